@@ -1,0 +1,207 @@
+/*
+ * rn_hip.h -- C-ABI of the MI355X (gfx950) ResNet forward path.
+ *
+ * Plain C: pointers, sizes and opaque handles only.  Every entry point returns
+ * an int status (RN_OK == 0) and never aborts; rn_last_error() gives the text.
+ * Device pointers are ordinary HIP device addresses (hipMalloc / rn_malloc /
+ * any framework's allocator on the same device).
+ *
+ * Each op entry point takes the arguments of the reference kernel it replaces,
+ * in the same order, preceded by the context:
+ *
+ *   rn_conv_output_size      <- convOutputSize            cuda/ops.cuh:9-13
+ *   rn_conv2d_forward        <- conv2dForwardKernel       cuda/ops.cuh:15-18  + Conv2d::forward      cuda/nn.cu:3-16
+ *   rn_maxpool2d_forward     <- maxPool2dKernel           cuda/ops.cuh:19-21  + Pool2d::maxforward   cuda/nn.cu:43-53
+ *   rn_avgpool2d_forward     <- avgPool2dKernel           cuda/ops.cuh:22-24  + Pool2d::avgforward   cuda/nn.cu:31-41
+ *   rn_linear_forward        <- linearForwardKernel       cuda/ops.cuh:25-26  + Linear::forward      cuda/nn.cu:55-64
+ *   rn_relu_forward          <- reluForwardKernel         cuda/ops.cuh:27     + reluForward          cuda/nn.cu:66-75
+ *   rn_batchnorm2d_forward   <- batchNorm2dForwardKernel  cuda/ops.cuh:29-31  + BatchNorm2d::forward cuda/nn.cu:18-29
+ *   rn_add_forward           <- addForwardKernel          cuda/ops.cuh:32     + addForward           cuda/nn.cu:77-87
+ *
+ * Buffers mirror Tensor<T> (cuda/tensor.cuh:59-245):
+ *   rn_malloc / rn_free          <- safeCudaMalloc / cudaFree deleter   helpers.cuh:24-35, tensor.cuh:81-86
+ *   rn_memcpy_h2d / rn_memcpy_d2h<- Tensor::toDevice                    tensor.cuh:184-199
+ *   rn_load_f32_file             <- Tensor::loadToCuda                  tensor.cuh:126-152
+ *   rn_save_f32_file             <- Tensor::save                        tensor.cuh:154-163
+ *   rn_sync                      <- cudaDeviceSynchronize + gpuAssert   nn.cu:14-15
+ *
+ * The model entry points replace the reference driver
+ * (cuda/inference/main.cu:53-226,243-251): createLayer/createResnet152,
+ * layerForward/resnet152Forward and the host argmax.
+ *
+ * Layout.  The reference is NCHW everywhere.  With the context in
+ * RN_LAYOUT_NCHW (default) every op reads and writes exactly what the
+ * reference kernel does.  The engine itself runs NHWC: in RN_LAYOUT_NHWC the
+ * same entry points take [B,H,W,C] activations (shape arguments unchanged),
+ * and rn_conv2d_nhwc_forward takes weights pre-packed by
+ * rn_conv2d_pack_weight plus an optional fused epilogue.
+ *
+ * Aliasing: out == inp is allowed for relu, batchnorm2d and add (out may alias
+ * inp1), as the reference driver uses them (main.cu:138,145-146,162-163).
+ * conv, pool and linear must not alias.
+ *
+ * Threading: one context per host thread; a context = (device, stream,
+ * scratch).  No global mutable state.
+ */
+#ifndef RN_HIP_H
+#define RN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define RN_API __attribute__((visibility("default")))
+#else
+#define RN_API
+#endif
+
+typedef struct rn_ctx rn_ctx;
+typedef struct rn_model rn_model;
+typedef struct rn_event rn_event;
+
+enum {
+    RN_OK = 0,
+    RN_ERR_INVALID = 1,     /* bad argument / shape precondition (reference: assert) */
+    RN_ERR_HIP = 2,         /* HIP runtime error (reference: gpuAssert -> abort)      */
+    RN_ERR_IO = 3,          /* file could not be opened / short read                  */
+    RN_ERR_NOMEM = 4,
+    RN_ERR_UNSUPPORTED = 5
+};
+
+enum { RN_LAYOUT_NCHW = 0, RN_LAYOUT_NHWC = 1 };
+
+/* forward modes of rn_model_forward */
+enum {
+    RN_FWD_REFERENCE_OPS = 0, /* one kernel per reference op, same sequence as main.cu:168-226 */
+    RN_FWD_FUSED = 1          /* BN / ReLU / residual add folded into the conv epilogue        */
+};
+
+/* ---- context ----------------------------------------------------------- */
+RN_API int rn_ctx_create(rn_ctx **out, int device, void *hip_stream /* NULL: own stream */);
+RN_API int rn_ctx_destroy(rn_ctx *ctx);
+RN_API int rn_ctx_set_layout(rn_ctx *ctx, int layout);
+RN_API int rn_ctx_get_layout(const rn_ctx *ctx);
+/* 1: synchronise and check after every op, like the reference (nn.cu:14-15). Default 0. */
+RN_API int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on);
+RN_API void *rn_ctx_stream(rn_ctx *ctx);
+RN_API int rn_ctx_device(const rn_ctx *ctx);
+RN_API int rn_sync(rn_ctx *ctx);
+RN_API const char *rn_last_error(const rn_ctx *ctx);
+RN_API const char *rn_status_string(int status);
+RN_API int rn_device_count(int *count);
+RN_API const char *rn_version(void);
+
+/* ---- buffers ------------------------------------------------------------ */
+RN_API int rn_malloc(rn_ctx *ctx, void **dev_ptr, uint64_t bytes);
+RN_API int rn_free(rn_ctx *ctx, void *dev_ptr);
+RN_API int rn_memcpy_h2d(rn_ctx *ctx, void *dev_dst, const void *host_src, uint64_t bytes);
+RN_API int rn_memcpy_d2h(rn_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
+RN_API int rn_memcpy_d2d(rn_ctx *ctx, void *dev_dst, const void *dev_src, uint64_t bytes);
+RN_API int rn_memset(rn_ctx *ctx, void *dev_ptr, int byte_value, uint64_t bytes);
+/* whole file -> new device buffer; numel = file_size / 4 (tensor.cuh:138) */
+RN_API int rn_load_f32_file(rn_ctx *ctx, const char *path, float **dev_ptr, uint64_t *numel);
+RN_API int rn_save_f32_file(rn_ctx *ctx, const char *path, const float *dev_ptr, uint64_t numel);
+
+/* ---- timing (HIP events on the context's stream) ------------------------ */
+RN_API int rn_event_create(rn_ctx *ctx, rn_event **out);
+RN_API int rn_event_destroy(rn_event *ev);
+RN_API int rn_event_record(rn_ctx *ctx, rn_event *ev);
+RN_API int rn_event_elapsed_ms(rn_event *start, rn_event *stop, float *ms); /* syncs on stop */
+
+/* ---- the seven reference ops -------------------------------------------- */
+RN_API uint64_t rn_conv_output_size(uint64_t x, uint64_t kernel_size, uint64_t stride,
+                                    uint64_t padding);
+RN_API int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *weight,
+                             uint64_t kernel_size, uint64_t stride, uint64_t padding,
+                             uint64_t h_out, uint64_t w_out, uint64_t B, uint64_t in_channels,
+                             uint64_t out_channels, uint64_t H, uint64_t W);
+RN_API int rn_maxpool2d_forward(rn_ctx *ctx, const float *inp, float *out, uint64_t kernel_size,
+                                uint64_t stride, uint64_t padding, uint64_t h_out, uint64_t w_out,
+                                uint64_t B, uint64_t channels, uint64_t H, uint64_t W);
+RN_API int rn_avgpool2d_forward(rn_ctx *ctx, const float *inp, float *out, uint64_t kernel_size,
+                                uint64_t stride, uint64_t padding, uint64_t h_out, uint64_t w_out,
+                                uint64_t B, uint64_t channels, uint64_t H, uint64_t W);
+RN_API int rn_linear_forward(rn_ctx *ctx, const float *inp, float *out, const float *weight,
+                             const float *bias /* nullable */, uint64_t B, uint64_t in_features,
+                             uint64_t out_features);
+RN_API int rn_relu_forward(rn_ctx *ctx, const float *inp, float *out, uint64_t N);
+RN_API int rn_batchnorm2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *weight,
+                                  const float *bias, const float *mean, const float *var,
+                                  uint64_t B, uint64_t C, uint64_t N);
+RN_API int rn_add_forward(rn_ctx *ctx, const float *inp1, const float *inp2, float *out,
+                          uint64_t N);
+/* host argmax of main.cu:243-251 as a device op: first maximum wins. idx is a device buffer. */
+RN_API int rn_argmax_forward(rn_ctx *ctx, const float *logits, uint64_t *idx, uint64_t B,
+                             uint64_t classes);
+
+/* ---- layout converters and weight packing -------------------------------- */
+RN_API int rn_nchw_to_nhwc(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t C,
+                           uint64_t H, uint64_t W);
+RN_API int rn_nhwc_to_nchw(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t C,
+                           uint64_t H, uint64_t W);
+/* channels of the engine-side input image for a convolution: in_channels, or 4 when
+ * in_channels < 4 (the 3-channel stem reads a [B,H,W,4] zero-padded image). */
+RN_API uint64_t rn_conv2d_input_channels(uint64_t in_channels);
+/* NCHW [B,C,H,W] -> NHWC with the channel dimension zero-padded to Cpad */
+RN_API int rn_nchw_to_nhwc_pad(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t C,
+                               uint64_t H, uint64_t W, uint64_t Cpad);
+RN_API uint64_t rn_conv2d_packed_weight_numel(uint64_t in_channels, uint64_t out_channels,
+                                              uint64_t kernel_size);
+/* OIHW (the weights_bin file order) -> K-major panel [Cout][kh][kw][Cin] the GEMM reads */
+RN_API int rn_conv2d_pack_weight(rn_ctx *ctx, const float *weight_oihw, float *packed,
+                                 uint64_t in_channels, uint64_t out_channels,
+                                 uint64_t kernel_size);
+/* scale = w / sqrt(var + 1e-5), shift = b - mean * scale, evaluated in double */
+RN_API int rn_batchnorm2d_fold(rn_ctx *ctx, const float *weight, const float *bias,
+                               const float *mean, const float *var, float *scale, float *shift,
+                               uint64_t C);
+
+typedef struct rn_epilogue {
+    const float *scale;    /* per out-channel multiplier, NULL = 1 */
+    const float *shift;    /* per out-channel addend,     NULL = 0 */
+    const float *residual; /* NHWC tensor of the output's shape added after scale/shift, NULL = none */
+    int relu;              /* apply max(x, 0) last */
+} rn_epilogue;
+
+/* NHWC in / NHWC out, packed weights, optional fused epilogue.  The input must have
+ * rn_conv2d_input_channels(in_channels) floats per pixel. */
+RN_API int rn_conv2d_nhwc_forward(rn_ctx *ctx, const float *inp, float *out,
+                                  const float *packed_weight, uint64_t kernel_size,
+                                  uint64_t stride, uint64_t padding, uint64_t h_out,
+                                  uint64_t w_out, uint64_t B, uint64_t in_channels,
+                                  uint64_t out_channels, uint64_t H, uint64_t W,
+                                  const rn_epilogue *epilogue /* nullable */);
+
+/* ---- model (main.cu driver) ---------------------------------------------- */
+/* arch: 50, 101 or 152 (block counts 3/4/6/3, 3/4/23/3, 3/8/36/3). */
+RN_API int rn_model_create(rn_ctx *ctx, rn_model **out, int arch);
+RN_API int rn_model_destroy(rn_model *m);
+/* state_dict key -> host data; numel must match the layer table. */
+RN_API int rn_model_set_tensor(rn_model *m, const char *key, const float *host_data,
+                               uint64_t numel);
+/* read every tensor from dir/<key> (the reference's weights_bin/ directory) */
+RN_API int rn_model_load_dir(rn_model *m, const char *weights_dir);
+/* upload-side work done once: pack conv weights, fold batch-norms */
+RN_API int rn_model_finalize(rn_model *m);
+/* names of the tensors the loader expects, one per call; returns NULL past the end */
+RN_API const char *rn_model_tensor_key(const rn_model *m, uint64_t index, uint64_t *numel);
+/* input: device NCHW [B,3,224,224]; logits: device [B,1000]. Asynchronous on the stream. */
+RN_API int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *logits,
+                            int mode);
+/* per-op timing of the next forwards: 1 = bracket every op with events */
+RN_API int rn_model_set_profiling(rn_model *m, int on);
+/* after a profiled forward + rn_sync: number of ops, then one record per op */
+RN_API uint64_t rn_model_profile_count(const rn_model *m);
+RN_API int rn_model_profile_get(const rn_model *m, uint64_t index, const char **op_name,
+                                const char **layer_name, float *ms, double *flops,
+                                double *bytes);
+RN_API uint64_t rn_model_activation_bytes(const rn_model *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RN_HIP_H */

@@ -1,0 +1,527 @@
+// conv2d and linear: the contraction kernels.
+//
+// Reference: conv2dForwardKernel (cuda/ops.cu:14-48) is a direct convolution, one
+// thread per output element, K = Cin*k*k global-load pairs each;
+// linearForwardKernel (ops.cu:110-128) the same for x.W^T + b.
+//
+// Here both are ONE implicit-GEMM kernel on the fp32 matrix cores of gfx950:
+//
+//     out[m][n] = sum_k A[m][k] * Wp[n][k]        m = (b, oh, ow), n = out channel
+//
+//  * activations are NHWC, so for a fixed kernel tap (kh, kw) the K slice of a row
+//    of A is a contiguous run of input channels: the K loop walks (kh, kw, 32-channel
+//    segment) and every A row of a K tile is one 128-byte read, or zeros when the
+//    tap falls into the padding (the reference skips those taps, ops.cu:35-37);
+//  * weights are pre-packed K-major [Cout][kh][kw][Cin] so B rows are 128-byte reads;
+//  * the 3-channel stem reads a [B,H,W,4] zero-padded image: one K segment is then
+//    8 consecutive pixels x 4 channels of one input row (kw slot 7 and channel 3
+//    carry zero weights), which turns the 7x7 stem into 7 K tiles of the same kernel;
+//  * v_mfma_f32_32x32x2_f32: exact fp32 products and sums (bitwise an fmaf chain in
+//    k order), 256 FLOP/clk/CU = the 157 TFLOP/s fp32 roof of the chip;
+//  * 256 threads = 4 waves as 2x2, each wave owns (BM/2)x(BN/2) as 32x32 MFMA tiles;
+//    operands staged through LDS as [rows][32 floats] images whose 16-byte chunks
+//    are XOR-swizzled with (row>>1)&7, which makes both the ds_write_b128 of the
+//    staging pass and the ds_read_b128 of the fragment reads bank-conflict free;
+//  * one ds_read_b128 feeds four MFMAs: lane (i, h) reads 4 consecutive k of row i
+//    at chunk 2*ks+h, MFMA j of the group consumes element j, i.e. k = 8ks+j from
+//    the low half-wave and 8ks+4+j from the high one -- A and B use the same map,
+//    so the sum is over the same k set in a fixed order;
+//  * register-staged double buffering: global loads of tile t+1 are issued before
+//    the MFMAs of tile t and written to the other LDS buffer after them; one
+//    barrier per K tile;
+//  * XCD-aware block order: each of the 8 XCDs gets a contiguous range of tiles with
+//    the N tiles of one M panel adjacent, so the A panel is re-read from that
+//    XCD's L2, not from HBM;
+//  * fused epilogue on the accumulator registers: per-channel scale/shift (folded
+//    batch-norm or fc bias), residual add, ReLU.
+//
+// Roofline: MFMA-bound for K*N/(K+N) above ~80 (every ResNet shape except the
+// 56x56 convs with 64 channels on one side, which are HBM-bound).  Algorithmic
+// bytes: 4*(M*K_in + N*K + M*N), flops 2*M*N*K.
+//
+// Shapes the GEMM cannot take (Cin not a multiple of 32 and not the small-Cin stem
+// form) run a direct kernel that keeps the reference's exact summation order
+// ic -> kh -> kw.
+#include "rn_internal.h"
+
+bool rn_conv_is_c4(uint64_t Cin, uint64_t k);
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmParams {
+    const float *in;
+    const float *w;
+    float *out;
+    const float *scale;
+    const float *shift;
+    const float *residual;
+    int relu;
+    int H, W, Cs;  // input height, width, floats per input pixel
+    int Ho, Wo, Cout;
+    int KH, KW;  // taps walked by the K loop (small-Cin form: KW = 1)
+    int stride, pad;
+    int cseg;      // 32-float segments per tap
+    int chunk_dw;  // small-Cin form: chunk c of a segment is pixel iw + c
+    int M;         // B * Ho * Wo
+    int Ktot;      // packed weight row length = KH * KW * cseg * 32
+    int nk;        // K tiles
+    int tiles_n;
+};
+
+constexpr int BK = 32;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
+{
+    constexpr int AP = BM / 32;  // A rows staged per thread
+    constexpr int BP = BN / 32;
+    constexpr int MI = BM / 64;  // 32x32 tiles per wave along M
+    constexpr int NI = BN / 64;
+    constexpr int STAGE = (BM + BN) * BK;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+    // XCD-aware tile order (bijective for any grid size)
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_n = (int)(logical % (unsigned)p.tiles_n);
+    const int tile_m = (int)(logical / (unsigned)p.tiles_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int t = threadIdx.x;
+    const int c = t & 7;    // 16-byte chunk of the 128-byte row this thread stages
+    const int r0 = t >> 3;  // first row; rows r0 + 32*j
+
+    // per staged A row: element offset of tap (0,0) chunk c, and input coordinates
+    int a_off[AP], a_ih[AP], a_iw[AP];
+    {
+        const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int j = 0; j < AP; ++j) {
+            const int m = m0 + r0 + 32 * j;
+            if (m < p.M) {
+                const int b = m / HoWo;
+                const int rem = m - b * HoWo;
+                const int oh = rem / p.Wo;
+                const int ow = rem - oh * p.Wo;
+                const int ih0 = oh * p.stride - p.pad;
+                const int iw0 = ow * p.stride - p.pad;
+                a_ih[j] = ih0;
+                a_iw[j] = iw0 + c * p.chunk_dw;
+                a_off[j] = ((b * p.H + ih0) * p.W + iw0) * p.Cs + c * 4;
+            } else {
+                a_ih[j] = -(1 << 28);  // fails every bounds check -> zero rows
+                a_iw[j] = 0;
+                a_off[j] = 0;
+            }
+        }
+    }
+    // per staged B row
+    const float *b_ptr[BP];
+    bool b_ok[BP];
+#pragma unroll
+    for (int j = 0; j < BP; ++j) {
+        const int n = n0 + r0 + 32 * j;
+        b_ok[j] = n < p.Cout;
+        b_ptr[j] = p.w + (size_t)(b_ok[j] ? n : 0) * p.Ktot + c * 4;
+    }
+
+    float4 ra[AP], rb[BP];
+    int kh = 0, kw = 0, cs = 0;  // K-loop position of the tile being LOADED
+
+    auto load_tile = [&](int kt) {
+        const int toff = (kh * p.W + kw) * p.Cs + cs * BK;
+#pragma unroll
+        for (int j = 0; j < AP; ++j) {
+            const bool ok = (unsigned)(a_ih[j] + kh) < (unsigned)p.H &&
+                            (unsigned)(a_iw[j] + kw) < (unsigned)p.W;
+            ra[j] = ok ? *reinterpret_cast<const float4 *>(p.in + (a_off[j] + toff))
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            rb[j] = b_ok[j] ? *reinterpret_cast<const float4 *>(b_ptr[j] + kt * BK)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // advance to the next tile: segment fastest, then kw, then kh
+        if (++cs == p.cseg) {
+            cs = 0;
+            if (++kw == p.KW) {
+                kw = 0;
+                ++kh;
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float *As = lds + buf * STAGE;
+        float *Bs = As + BM * BK;
+#pragma unroll
+        for (int j = 0; j < AP; ++j) {
+            const int row = r0 + 32 * j;
+            const int pc = c ^ ((row >> 1) & 7);
+            *reinterpret_cast<float4 *>(As + row * BK + pc * 4) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BP; ++j) {
+            const int row = r0 + 32 * j;
+            const int pc = c ^ ((row >> 1) & 7);
+            *reinterpret_cast<float4 *>(Bs + row * BK + pc * 4) = rb[j];
+        }
+    };
+
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int sw = (li >> 1) & 7;  // swizzle term of this lane's fragment rows
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    auto compute_tile = [&](int buf) {
+        const float *As = lds + buf * STAGE + (wr * (BM / 2) + li) * BK;
+        const float *Bs = lds + buf * STAGE + BM * BK + (wc * (BN / 2) + li) * BK;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int pc = ((2 * ks + lh) ^ sw) * 4;
+            float4 a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                a[mi] = *reinterpret_cast<const float4 *>(As + mi * 32 * BK + pc);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                b[ni] = *reinterpret_cast<const float4 *>(Bs + ni * 32 * BK + pc);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    acc[mi][ni] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < p.nk; ++kt) {
+        const bool more = kt + 1 < p.nk;
+        if (more) load_tile(kt + 1);
+        compute_tile(kt & 1);
+        if (more) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int n = n0 + wc * (BN / 2) + ni * 32 + li;
+        if (n >= p.Cout) continue;
+        const float sc = p.scale ? p.scale[n] : 1.f;
+        const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int mb = m0 + wr * (BM / 2) + mi * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < p.M) {
+                    const size_t o = (size_t)m * p.Cout + n;
+                    float v = acc[mi][ni][e];
+                    if (p.scale) {
+                        v = fmaf(v, sc, sh);
+                    } else if (p.shift) {
+                        v += sh;
+                    }
+                    if (p.residual) v += p.residual[o];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// any shape: one thread per output element, the reference's loop order and one fp32
+// fmaf chain (ops.cu:30-45), lanes along the contiguous output dimension.
+struct DirectParams {
+    const float *in;
+    const float *w;
+    float *out;
+    const float *scale;
+    const float *shift;
+    const float *residual;
+    int relu;
+    int k, stride, pad, Ho, Wo, Cin, Cs, Cout, H, W;
+    int nhwc;      // activation layout
+    int w_packed;  // 0: OIHW, 1: [Cout][kh][kw][Cin], 2: small-Cin panel [Cout][kh][8][4]
+    uint64_t total;
+};
+
+__global__ __launch_bounds__(256) void conv_direct_kernel(const DirectParams p)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < p.total; i += gstride) {
+        int oc, oh, ow;
+        uint64_t b;
+        if (p.nhwc) {
+            oc = (int)(i % (uint64_t)p.Cout);
+            uint64_t q = i / (uint64_t)p.Cout;
+            ow = (int)(q % (uint64_t)p.Wo);
+            q /= (uint64_t)p.Wo;
+            oh = (int)(q % (uint64_t)p.Ho);
+            b = q / (uint64_t)p.Ho;
+        } else {
+            ow = (int)(i % (uint64_t)p.Wo);
+            uint64_t q = i / (uint64_t)p.Wo;
+            oh = (int)(q % (uint64_t)p.Ho);
+            q /= (uint64_t)p.Ho;
+            oc = (int)(q % (uint64_t)p.Cout);
+            b = q / (uint64_t)p.Cout;
+        }
+        const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+        float sum = 0.f;
+        for (int ic = 0; ic < p.Cin; ++ic) {
+            for (int kh = 0; kh < p.k; ++kh) {
+                const int ih = ih0 + kh;
+                if (ih < 0 || ih >= p.H) continue;
+                for (int kw = 0; kw < p.k; ++kw) {
+                    const int iw = iw0 + kw;
+                    if (iw < 0 || iw >= p.W) continue;
+                    const uint64_t ii = p.nhwc ? (((b * p.H + ih) * p.W + iw) * p.Cs + ic)
+                                               : (((b * p.Cin + ic) * p.H + ih) * p.W + iw);
+                    uint64_t wi;
+                    if (p.w_packed == 0)
+                        wi = (((uint64_t)oc * p.Cin + ic) * p.k + kh) * p.k + kw;
+                    else if (p.w_packed == 1)
+                        wi = (((uint64_t)oc * p.k + kh) * p.k + kw) * p.Cin + ic;
+                    else
+                        wi = (((uint64_t)oc * p.k + kh) * 8 + kw) * 4 + ic;
+                    sum = fmaf(p.in[ii], p.w[wi], sum);
+                }
+            }
+        }
+        if (p.scale) {
+            sum = fmaf(sum, p.scale[oc], p.shift ? p.shift[oc] : 0.f);
+        } else if (p.shift) {
+            sum += p.shift[oc];
+        }
+        if (p.residual) sum += p.residual[i];
+        if (p.relu) sum = fmaxf(sum, 0.f);
+        p.out[i] = sum;
+    }
+}
+
+bool fits_i32(uint64_t v) { return v < (1ull << 31); }
+
+// GEMM launch on NHWC data with packed weights.  Caller has checked eligibility.
+int launch_gemm(rn_ctx *ctx, const float *inp, float *out, const float *packed, uint64_t k,
+                uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out, uint64_t B,
+                uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W, const rn_epilogue *ep,
+                const char *what)
+{
+    GemmParams p;
+    p.in = inp;
+    p.w = packed;
+    p.out = out;
+    p.scale = ep ? ep->scale : nullptr;
+    p.shift = ep ? ep->shift : nullptr;
+    p.residual = ep ? ep->residual : nullptr;
+    p.relu = ep ? ep->relu : 0;
+    const bool c4 = rn_conv_is_c4(Cin, k);
+    p.H = (int)H;
+    p.W = (int)W;
+    p.Cs = c4 ? 4 : (int)Cin;
+    p.Ho = (int)h_out;
+    p.Wo = (int)w_out;
+    p.Cout = (int)Cout;
+    p.KH = (int)k;
+    p.KW = c4 ? 1 : (int)k;
+    p.stride = (int)stride;
+    p.pad = (int)pad;
+    p.cseg = c4 ? 1 : (int)(Cin / 32);
+    p.chunk_dw = c4 ? 1 : 0;
+    p.M = (int)(B * h_out * w_out);
+    p.nk = p.KH * p.KW * p.cseg;
+    p.Ktot = p.nk * BK;
+
+    const bool narrow = Cout <= 64;
+    const int BNsel = narrow ? 64 : 128;
+    const uint64_t tiles_n = rn_ceil_div(Cout, BNsel);
+    // prefer 128-row tiles; drop to 64 rows when that would leave CUs idle
+    const bool small = rn_ceil_div((uint64_t)p.M, 128) * tiles_n < 768;
+    const int BMsel = small ? 64 : 128;
+    const uint64_t tiles_m = rn_ceil_div((uint64_t)p.M, BMsel);
+    p.tiles_n = (int)tiles_n;
+    const uint64_t grid = tiles_m * tiles_n;
+    RN_REQUIRE(ctx, fits_i32(grid), "too many tiles");
+    dim3 g((unsigned)grid), blk(256);
+    if (BMsel == 128 && BNsel == 128)
+        conv_gemm_kernel<128, 128><<<g, blk, 0, ctx->stream>>>(p);
+    else if (BMsel == 128 && BNsel == 64)
+        conv_gemm_kernel<128, 64><<<g, blk, 0, ctx->stream>>>(p);
+    else if (BMsel == 64 && BNsel == 128)
+        conv_gemm_kernel<64, 128><<<g, blk, 0, ctx->stream>>>(p);
+    else
+        conv_gemm_kernel<64, 64><<<g, blk, 0, ctx->stream>>>(p);
+    return rn_after_launch(ctx, what);
+}
+
+int launch_direct(rn_ctx *ctx, const float *inp, float *out, const float *w, uint64_t k,
+                  uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out, uint64_t B,
+                  uint64_t Cin, uint64_t Cs, uint64_t Cout, uint64_t H, uint64_t W, int nhwc,
+                  int w_packed, const rn_epilogue *ep, const char *what)
+{
+    DirectParams p;
+    p.in = inp;
+    p.w = w;
+    p.out = out;
+    p.scale = ep ? ep->scale : nullptr;
+    p.shift = ep ? ep->shift : nullptr;
+    p.residual = ep ? ep->residual : nullptr;
+    p.relu = ep ? ep->relu : 0;
+    p.k = (int)k;
+    p.stride = (int)stride;
+    p.pad = (int)pad;
+    p.Ho = (int)h_out;
+    p.Wo = (int)w_out;
+    p.Cin = (int)Cin;
+    p.Cs = (int)Cs;
+    p.Cout = (int)Cout;
+    p.H = (int)H;
+    p.W = (int)W;
+    p.nhwc = nhwc;
+    p.w_packed = w_packed;
+    p.total = B * Cout * h_out * w_out;
+    conv_direct_kernel<<<rn_stream_grid(p.total, 256), 256, 0, ctx->stream>>>(p);
+    return rn_after_launch(ctx, what);
+}
+
+int check_conv_args(rn_ctx *ctx, const float *inp, const float *out, const float *weight,
+                    uint64_t k, uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out,
+                    uint64_t B, uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W)
+{
+    RN_REQUIRE(ctx, inp && out && weight, "null tensor");
+    RN_REQUIRE(ctx, inp != out, "conv2d cannot run in place");
+    RN_REQUIRE(ctx, k >= 1 && stride >= 1, "kernel_size and stride must be >= 1");
+    RN_REQUIRE(ctx, k < (1u << 12) && stride < (1u << 12) && pad < (1u << 12), "dimension too large");
+    const uint64_t cs = Cin < 4 ? 4 : Cin;
+    RN_REQUIRE(ctx, fits_i32(B * H * W * cs) && fits_i32(B * h_out * w_out * Cout) &&
+                        fits_i32(Cout * k * k * cs + 64),
+               "tensor has 2^31 or more elements");
+    return RN_OK;
+}
+
+bool gemm_eligible(const void *inp, const void *out, const void *w, uint64_t Cin, uint64_t k)
+{
+    const bool al = ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out) |
+                      reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+    return al && (Cin % 32 == 0 || rn_conv_is_c4(Cin, k));
+}
+
+}  // namespace
+
+extern "C" {
+
+int rn_conv2d_nhwc_forward(rn_ctx *ctx, const float *inp, float *out, const float *packed_weight,
+                           uint64_t kernel_size, uint64_t stride, uint64_t padding, uint64_t h_out,
+                           uint64_t w_out, uint64_t B, uint64_t in_channels, uint64_t out_channels,
+                           uint64_t H, uint64_t W, const rn_epilogue *epilogue)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (B * out_channels * h_out * w_out == 0) return RN_OK;
+    RN_TRY(check_conv_args(ctx, inp, out, packed_weight, kernel_size, stride, padding, h_out, w_out,
+                           B, in_channels, out_channels, H, W));
+    RN_REQUIRE(ctx, in_channels >= 1, "in_channels must be >= 1");
+    if (epilogue && epilogue->residual)
+        RN_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(epilogue->residual) & 3) == 0,
+                   "misaligned residual");
+    if (gemm_eligible(inp, out, packed_weight, in_channels, kernel_size)) {
+        return launch_gemm(ctx, inp, out, packed_weight, kernel_size, stride, padding, h_out, w_out,
+                           B, in_channels, out_channels, H, W, epilogue, "rn_conv2d_nhwc_forward");
+    }
+    const bool c4 = rn_conv_is_c4(in_channels, kernel_size);
+    return launch_direct(ctx, inp, out, packed_weight, kernel_size, stride, padding, h_out, w_out,
+                         B, in_channels, rn_conv2d_input_channels(in_channels), out_channels, H, W,
+                         1, c4 ? 2 : 1, epilogue, "rn_conv2d_nhwc_forward(direct)");
+}
+
+int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *weight,
+                      uint64_t kernel_size, uint64_t stride, uint64_t padding, uint64_t h_out,
+                      uint64_t w_out, uint64_t B, uint64_t in_channels, uint64_t out_channels,
+                      uint64_t H, uint64_t W)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (B * out_channels * h_out * w_out == 0) return RN_OK;
+    RN_TRY(check_conv_args(ctx, inp, out, weight, kernel_size, stride, padding, h_out, w_out, B,
+                           in_channels, out_channels, H, W));
+    RN_REQUIRE(ctx, in_channels >= 1, "in_channels must be >= 1");
+    const bool c4 = rn_conv_is_c4(in_channels, kernel_size);
+    const bool fast = in_channels % 32 == 0 || c4;
+    if (!fast || (ctx->layout == RN_LAYOUT_NHWC && in_channels < 4)) {
+        // exact reference order; OIHW weights as given
+        return launch_direct(ctx, inp, out, weight, kernel_size, stride, padding, h_out, w_out, B,
+                             in_channels, in_channels, out_channels, H, W,
+                             ctx->layout == RN_LAYOUT_NHWC, 0, nullptr,
+                             "rn_conv2d_forward(direct)");
+    }
+    const uint64_t wn = rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size);
+    void *wp = nullptr;
+    RN_TRY(rn_scratch(ctx, 1, wn * sizeof(float), &wp));
+    RN_TRY(rn_conv2d_pack_weight(ctx, weight, (float *)wp, in_channels, out_channels, kernel_size));
+    if (ctx->layout == RN_LAYOUT_NHWC) {
+        return launch_gemm(ctx, inp, out, (const float *)wp, kernel_size, stride, padding, h_out,
+                           w_out, B, in_channels, out_channels, H, W, nullptr,
+                           "rn_conv2d_forward(nhwc)");
+    }
+    // NCHW caller: transpose in, contract, transpose out
+    const uint64_t cs = rn_conv2d_input_channels(in_channels);
+    void *xin = nullptr, *xout = nullptr;
+    RN_TRY(rn_scratch(ctx, 2, B * H * W * cs * sizeof(float), &xin));
+    RN_TRY(rn_scratch(ctx, 3, B * h_out * w_out * out_channels * sizeof(float), &xout));
+    if (cs != in_channels) {
+        RN_TRY(rn_nchw_to_nhwc_pad(ctx, inp, (float *)xin, B, in_channels, H, W, cs));
+    } else {
+        RN_TRY(rn_nchw_to_nhwc(ctx, inp, (float *)xin, B, in_channels, H, W));
+    }
+    RN_TRY(launch_gemm(ctx, (const float *)xin, (float *)xout, (const float *)wp, kernel_size,
+                       stride, padding, h_out, w_out, B, in_channels, out_channels, H, W, nullptr,
+                       "rn_conv2d_forward(gemm)"));
+    return rn_nhwc_to_nchw(ctx, (const float *)xout, out, B, out_channels, h_out, w_out);
+}
+
+int rn_linear_forward(rn_ctx *ctx, const float *inp, float *out, const float *weight,
+                      const float *bias, uint64_t B, uint64_t in_features, uint64_t out_features)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (B * out_features == 0) return RN_OK;
+    RN_REQUIRE(ctx, inp && out && weight, "null tensor");
+    RN_REQUIRE(ctx, inp != out, "linear cannot run in place");
+    RN_REQUIRE(ctx, in_features >= 1, "in_features must be >= 1");
+    RN_REQUIRE(ctx, fits_i32(B * in_features) && fits_i32(B * out_features) &&
+                        fits_i32(out_features * in_features + 64),
+               "tensor has 2^31 or more elements");
+    rn_epilogue ep = {nullptr, bias, nullptr, 0};
+    // W is [out][in] row-major == the K-major panel of a 1x1 convolution on a 1x1 image
+    if (in_features % 32 == 0 && gemm_eligible(inp, out, weight, in_features, 1)) {
+        return launch_gemm(ctx, inp, out, weight, 1, 1, 0, 1, 1, B, in_features, out_features, 1, 1,
+                           &ep, "rn_linear_forward");
+    }
+    return launch_direct(ctx, inp, out, weight, 1, 1, 0, 1, 1, B, in_features, in_features,
+                         out_features, 1, 1, 1, 0, &ep, "rn_linear_forward(direct)");
+}
+
+}  // extern "C"

@@ -1,0 +1,310 @@
+// Context, buffers, file I/O and events: the Tensor / helpers side of the boundary
+// (reference cuda/tensor.cuh:59-245, cuda/helpers.cuh:6-35), as status-returning C.
+#include <errno.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rn_internal.h"
+
+int rn_set_error(rn_ctx *ctx, int status, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return status;
+}
+
+int rn_check_hip(rn_ctx *ctx, hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return RN_OK;
+    return rn_set_error(ctx, RN_ERR_HIP, "HIP error %d (%s) in %s", (int)e, hipGetErrorString(e),
+                        what);
+}
+
+int rn_after_launch(rn_ctx *ctx, const char *what)
+{
+    RN_TRY(rn_check_hip(ctx, hipGetLastError(), what));
+    if (ctx->sync_each_op) {
+        RN_TRY(rn_check_hip(ctx, hipStreamSynchronize(ctx->stream), what));
+    }
+    return RN_OK;
+}
+
+int rn_scratch(rn_ctx *ctx, int slot, uint64_t bytes, void **ptr)
+{
+    if (slot < 0 || slot >= 4) return rn_set_error(ctx, RN_ERR_INVALID, "bad scratch slot");
+    if (ctx->scratch_bytes[slot] < bytes) {
+        // the old block may still be in use by queued kernels
+        RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch[slot]) RN_HIP_TRY(ctx, hipFree(ctx->scratch[slot]));
+        ctx->scratch[slot] = nullptr;
+        ctx->scratch_bytes[slot] = 0;
+        uint64_t want = (bytes + 255) & ~(uint64_t)255;
+        RN_HIP_TRY(ctx, hipMalloc(&ctx->scratch[slot], want));
+        ctx->scratch_bytes[slot] = want;
+    }
+    *ptr = ctx->scratch[slot];
+    return RN_OK;
+}
+
+extern "C" {
+
+const char *rn_version(void) { return "resnet.c_amd 0.1 (gfx950)"; }
+
+const char *rn_status_string(int status)
+{
+    switch (status) {
+        case RN_OK: return "ok";
+        case RN_ERR_INVALID: return "invalid argument";
+        case RN_ERR_HIP: return "HIP runtime error";
+        case RN_ERR_IO: return "I/O error";
+        case RN_ERR_NOMEM: return "out of memory";
+        case RN_ERR_UNSUPPORTED: return "unsupported";
+        default: return "unknown status";
+    }
+}
+
+int rn_device_count(int *count)
+{
+    if (!count) return RN_ERR_INVALID;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return RN_ERR_HIP;
+    }
+    return RN_OK;
+}
+
+int rn_ctx_create(rn_ctx **out, int device, void *hip_stream)
+{
+    if (!out) return RN_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RN_ERR_HIP;
+    if (device < 0 || device >= n) return RN_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return RN_ERR_HIP;
+    rn_ctx *ctx = (rn_ctx *)calloc(1, sizeof(rn_ctx));
+    if (!ctx) return RN_ERR_NOMEM;
+    ctx->device = device;
+    ctx->layout = RN_LAYOUT_NCHW;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            free(ctx);
+            return RN_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return RN_OK;
+}
+
+int rn_ctx_destroy(rn_ctx *ctx)
+{
+    if (!ctx) return RN_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 4; ++i) {
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    free(ctx);
+    return RN_OK;
+}
+
+int rn_ctx_set_layout(rn_ctx *ctx, int layout)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (layout != RN_LAYOUT_NCHW && layout != RN_LAYOUT_NHWC)
+        return rn_set_error(ctx, RN_ERR_INVALID, "unknown layout %d", layout);
+    ctx->layout = layout;
+    return RN_OK;
+}
+
+int rn_ctx_get_layout(const rn_ctx *ctx) { return ctx ? ctx->layout : -1; }
+
+int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    ctx->sync_each_op = on ? 1 : 0;
+    return RN_OK;
+}
+
+void *rn_ctx_stream(rn_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int rn_ctx_device(const rn_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int rn_sync(rn_ctx *ctx)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    RN_HIP_TRY(ctx, hipGetLastError());
+    return RN_OK;
+}
+
+const char *rn_last_error(const rn_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+
+int rn_malloc(rn_ctx *ctx, void **dev_ptr, uint64_t bytes)
+{
+    if (!ctx || !dev_ptr) return RN_ERR_INVALID;
+    *dev_ptr = nullptr;
+    if (bytes == 0) return RN_OK;  // empty tensor: null data (tensor.cuh:62-65)
+    RN_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dev_ptr, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        return rn_set_error(ctx, RN_ERR_NOMEM, "hipMalloc(%llu) out of memory",
+                            (unsigned long long)bytes);
+    }
+    return rn_check_hip(ctx, e, "hipMalloc");
+}
+
+int rn_free(rn_ctx *ctx, void *dev_ptr)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (!dev_ptr) return RN_OK;
+    RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    RN_HIP_TRY(ctx, hipFree(dev_ptr));
+    return RN_OK;
+}
+
+int rn_memcpy_h2d(rn_ctx *ctx, void *dev_dst, const void *host_src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!dev_dst || !host_src))) return RN_ERR_INVALID;
+    if (!bytes) return RN_OK;
+    RN_HIP_TRY(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RN_OK;
+}
+
+int rn_memcpy_d2h(rn_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!host_dst || !dev_src))) return RN_ERR_INVALID;
+    if (!bytes) return RN_OK;
+    RN_HIP_TRY(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RN_OK;
+}
+
+int rn_memcpy_d2d(rn_ctx *ctx, void *dev_dst, const void *dev_src, uint64_t bytes)
+{
+    if (!ctx || (bytes && (!dev_dst || !dev_src))) return RN_ERR_INVALID;
+    if (!bytes) return RN_OK;
+    RN_HIP_TRY(ctx,
+               hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return RN_OK;
+}
+
+int rn_memset(rn_ctx *ctx, void *dev_ptr, int byte_value, uint64_t bytes)
+{
+    if (!ctx || (bytes && !dev_ptr)) return RN_ERR_INVALID;
+    if (!bytes) return RN_OK;
+    RN_HIP_TRY(ctx, hipMemsetAsync(dev_ptr, byte_value, bytes, ctx->stream));
+    return RN_OK;
+}
+
+int rn_load_f32_file(rn_ctx *ctx, const char *path, float **dev_ptr, uint64_t *numel)
+{
+    if (!ctx || !path || !dev_ptr || !numel) return RN_ERR_INVALID;
+    *dev_ptr = nullptr;
+    *numel = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) return rn_set_error(ctx, RN_ERR_IO, "Can't open %s: %s", path, strerror(errno));
+    if (fseek(f, 0, SEEK_END) != 0) {
+        fclose(f);
+        return rn_set_error(ctx, RN_ERR_IO, "seek failed on %s", path);
+    }
+    long sz = ftell(f);
+    rewind(f);
+    uint64_t n = sz > 0 ? (uint64_t)sz / sizeof(float) : 0;
+    if (n == 0) {
+        fclose(f);
+        return rn_set_error(ctx, RN_ERR_IO, "%s holds no floats", path);
+    }
+    float *host = (float *)malloc(n * sizeof(float));
+    if (!host) {
+        fclose(f);
+        return rn_set_error(ctx, RN_ERR_NOMEM, "host buffer for %s", path);
+    }
+    size_t got = fread(host, sizeof(float), n, f);
+    fclose(f);
+    if (got != n) {
+        free(host);
+        return rn_set_error(ctx, RN_ERR_IO, "short read on %s", path);
+    }
+    void *d = nullptr;
+    int st = rn_malloc(ctx, &d, n * sizeof(float));
+    if (st == RN_OK) st = rn_memcpy_h2d(ctx, d, host, n * sizeof(float));
+    free(host);
+    if (st != RN_OK) {
+        if (d) (void)hipFree(d);
+        return st;
+    }
+    *dev_ptr = (float *)d;
+    *numel = n;
+    return RN_OK;
+}
+
+int rn_save_f32_file(rn_ctx *ctx, const char *path, const float *dev_ptr, uint64_t numel)
+{
+    if (!ctx || !path || (numel && !dev_ptr)) return RN_ERR_INVALID;
+    float *host = (float *)malloc(numel ? numel * sizeof(float) : 1);
+    if (!host) return rn_set_error(ctx, RN_ERR_NOMEM, "host buffer for %s", path);
+    int st = rn_memcpy_d2h(ctx, host, dev_ptr, numel * sizeof(float));
+    if (st == RN_OK) {
+        FILE *f = fopen(path, "wb");
+        if (!f) {
+            st = rn_set_error(ctx, RN_ERR_IO, "Can't open %s: %s", path, strerror(errno));
+        } else {
+            if (fwrite(host, sizeof(float), numel, f) != numel)
+                st = rn_set_error(ctx, RN_ERR_IO, "short write on %s", path);
+            fclose(f);
+        }
+    }
+    free(host);
+    return st;
+}
+
+int rn_event_create(rn_ctx *ctx, rn_event **out)
+{
+    if (!ctx || !out) return RN_ERR_INVALID;
+    rn_event *ev = (rn_event *)calloc(1, sizeof(rn_event));
+    if (!ev) return RN_ERR_NOMEM;
+    int st = rn_check_hip(ctx, hipEventCreate(&ev->ev), "hipEventCreate");
+    if (st != RN_OK) {
+        free(ev);
+        return st;
+    }
+    *out = ev;
+    return RN_OK;
+}
+
+int rn_event_destroy(rn_event *ev)
+{
+    if (!ev) return RN_OK;
+    (void)hipEventDestroy(ev->ev);
+    free(ev);
+    return RN_OK;
+}
+
+int rn_event_record(rn_ctx *ctx, rn_event *ev)
+{
+    if (!ctx || !ev) return RN_ERR_INVALID;
+    RN_HIP_TRY(ctx, hipEventRecord(ev->ev, ctx->stream));
+    return RN_OK;
+}
+
+int rn_event_elapsed_ms(rn_event *start, rn_event *stop, float *ms)
+{
+    if (!start || !stop || !ms) return RN_ERR_INVALID;
+    if (hipEventSynchronize(stop->ev) != hipSuccess) return RN_ERR_HIP;
+    if (hipEventElapsedTime(ms, start->ev, stop->ev) != hipSuccess) return RN_ERR_HIP;
+    return RN_OK;
+}
+
+}  // extern "C"

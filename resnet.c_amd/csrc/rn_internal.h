@@ -1,0 +1,67 @@
+// Internal definitions shared by the HIP translation units of librn_hip.so.
+#ifndef RN_INTERNAL_H
+#define RN_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "rn_hip.h"
+
+struct rn_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    int layout;
+    int sync_each_op;
+    // scratch grown on demand (never inside a graph capture; callers that capture
+    // warm up first so the sizes are already settled)
+    void *scratch[4];
+    uint64_t scratch_bytes[4];
+    char err[512];
+};
+
+struct rn_event {
+    hipEvent_t ev;
+};
+
+int rn_set_error(rn_ctx *ctx, int status, const char *fmt, ...);
+int rn_check_hip(rn_ctx *ctx, hipError_t e, const char *what);
+// scratch slot `slot` with at least `bytes`; contents undefined
+int rn_scratch(rn_ctx *ctx, int slot, uint64_t bytes, void **ptr);
+// launch epilogue shared by every op: launch-error check and optional per-op sync
+int rn_after_launch(rn_ctx *ctx, const char *what);
+
+#define RN_HIP_TRY(ctx, expr)                                  \
+    do {                                                       \
+        int rn_st_ = rn_check_hip((ctx), (expr), #expr);       \
+        if (rn_st_ != RN_OK) return rn_st_;                    \
+    } while (0)
+
+#define RN_TRY(expr)                       \
+    do {                                   \
+        int rn_st_ = (expr);               \
+        if (rn_st_ != RN_OK) return rn_st_; \
+    } while (0)
+
+#define RN_REQUIRE(ctx, cond, msg)                                   \
+    do {                                                             \
+        if (!(cond)) return rn_set_error((ctx), RN_ERR_INVALID, "%s: %s", __func__, (msg)); \
+    } while (0)
+
+static inline uint64_t rn_ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// grid for a grid-stride bandwidth kernel: enough blocks to fill 256 CUs x 8, no more
+static inline unsigned rn_stream_grid(uint64_t work_items, unsigned block)
+{
+    uint64_t g = rn_ceil_div(work_items, block);
+    if (g > 2048) g = 2048;
+    if (g == 0) g = 1;
+    return (unsigned)g;
+}
+
+// small-Cin ("stem") form of the contraction: Cin <= 4 and k <= 8
+bool rn_conv_is_c4(uint64_t Cin, uint64_t k);
+
+
+#endif

@@ -1,0 +1,191 @@
+// Layout converters between the reference's NCHW / OIHW world and the engine's
+// NHWC activations and K-major weight panels.  None of this exists in the
+// reference (it is NCHW end to end, cuda/ops.cu:3-7); it is the price of the
+// MI355X-first data layout and is paid once per weight at load time and once per
+// network input.
+#include "rn_internal.h"
+
+namespace {
+
+constexpr int kTile = 32;
+
+// src viewed as [batch][R][S] row-major -> dst [batch][S][R].  NCHW->NHWC is R=C,
+// S=H*W; NHWC->NCHW is R=H*W, S=C.  32x32 tile through LDS (+1 pad: conflict-free
+// column reads), 32x8 threads, both global sides coalesced along their inner dim.
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src,
+                                                        float *__restrict__ dst, uint32_t R,
+                                                        uint32_t S)
+{
+    __shared__ float tile[kTile][kTile + 1];
+    const uint64_t img = (uint64_t)blockIdx.z * R * S;
+    const uint32_t s0 = blockIdx.x * kTile, r0 = blockIdx.y * kTile;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (uint32_t j = ty; j < kTile; j += 8) {
+        const uint32_t r = r0 + j, s = s0 + tx;
+        if (r < R && s < S) tile[j][tx] = src[img + (uint64_t)r * S + s];
+    }
+    __syncthreads();
+    for (uint32_t j = ty; j < kTile; j += 8) {
+        const uint32_t s = s0 + j, r = r0 + tx;
+        if (r < R && s < S) dst[img + (uint64_t)s * R + r] = tile[tx][j];
+    }
+}
+
+// NCHW [B,C,HW] -> NHWC [B,HW,4], channels >= C zero-filled.  One float4 per pixel.
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float *__restrict__ src,
+                                                            float4 *__restrict__ dst, uint32_t C,
+                                                            uint32_t HW, uint64_t total_pix)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < total_pix; p += gstride) {
+        const uint64_t b = p / HW;
+        const uint32_t hw = (uint32_t)(p - b * HW);
+        const float *s = src + b * C * HW + hw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x = s[0];
+        if (C > 1) v.y = s[HW];
+        if (C > 2) v.z = s[2 * (uint64_t)HW];
+        if (C > 3) v.w = s[3 * (uint64_t)HW];
+        dst[p] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float *__restrict__ src,
+                                                               float *__restrict__ dst,
+                                                               uint32_t C, uint32_t HW,
+                                                               uint32_t Cpad, uint64_t total)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+        const uint32_t c = (uint32_t)(i % Cpad);
+        const uint64_t p = i / Cpad;
+        const uint64_t b = p / HW;
+        const uint32_t hw = (uint32_t)(p - b * HW);
+        dst[i] = c < C ? src[(b * C + c) * HW + hw] : 0.f;
+    }
+}
+
+// OIHW -> [Cout][kh][kw][Cin]
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w,
+                                                          float *__restrict__ packed, uint32_t Cin,
+                                                          uint32_t k, uint64_t total)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    const uint32_t kk = k * k;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+        const uint32_t ic = (uint32_t)(i % Cin);
+        uint64_t r = i / Cin;
+        const uint32_t tap = (uint32_t)(r % kk);
+        const uint64_t oc = r / kk;
+        packed[i] = w[(oc * Cin + ic) * kk + tap];
+    }
+}
+
+// small-Cin ("stem") panel: [Cout][kh][8 kw slots][4 channel slots], zero where kw >= k
+// or ic >= Cin, so one 32-float K segment = 8 consecutive pixels of a 4-channel image
+__global__ __launch_bounds__(256) void pack_weight_c4_kernel(const float *__restrict__ w,
+                                                             float *__restrict__ packed,
+                                                             uint32_t Cin, uint32_t k,
+                                                             uint64_t total)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+        const uint32_t ic = (uint32_t)(i & 3);
+        const uint32_t kw = (uint32_t)((i >> 2) & 7);
+        const uint64_t r = i >> 5;
+        const uint32_t kh = (uint32_t)(r % k);
+        const uint64_t oc = r / k;
+        packed[i] = (ic < Cin && kw < k) ? w[((oc * Cin + ic) * k + kh) * k + kw] : 0.f;
+    }
+}
+
+}  // namespace
+
+bool rn_conv_is_c4(uint64_t Cin, uint64_t k) { return Cin <= 4 && k <= 8; }
+
+extern "C" {
+
+uint64_t rn_conv2d_input_channels(uint64_t in_channels)
+{
+    return in_channels < 4 ? 4 : in_channels;
+}
+
+uint64_t rn_conv2d_packed_weight_numel(uint64_t in_channels, uint64_t out_channels,
+                                       uint64_t kernel_size)
+{
+    if (rn_conv_is_c4(in_channels, kernel_size)) return out_channels * kernel_size * 32;
+    return out_channels * kernel_size * kernel_size * in_channels;
+}
+
+int rn_conv2d_pack_weight(rn_ctx *ctx, const float *weight_oihw, float *packed,
+                          uint64_t in_channels, uint64_t out_channels, uint64_t kernel_size)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    const uint64_t total = rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size);
+    if (total == 0) return RN_OK;
+    RN_REQUIRE(ctx, weight_oihw && packed && weight_oihw != packed, "null or aliased tensor");
+    RN_REQUIRE(ctx, in_channels < (1u << 30) && kernel_size < (1u << 15), "dimension too large");
+    if (rn_conv_is_c4(in_channels, kernel_size)) {
+        pack_weight_c4_kernel<<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
+            weight_oihw, packed, (uint32_t)in_channels, (uint32_t)kernel_size, total);
+    } else {
+        pack_weight_kernel<<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
+            weight_oihw, packed, (uint32_t)in_channels, (uint32_t)kernel_size, total);
+    }
+    return rn_after_launch(ctx, "rn_conv2d_pack_weight");
+}
+
+static int transpose_launch(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t R,
+                            uint64_t S, const char *what)
+{
+    if (B * R * S == 0) return RN_OK;
+    RN_REQUIRE(ctx, src && dst && src != dst, "null or aliased tensor");
+    RN_REQUIRE(ctx, R < (1ull << 31) && S < (1ull << 31), "dimension too large");
+    const uint64_t gy = rn_ceil_div(R, kTile);
+    RN_REQUIRE(ctx, gy <= 65535, "too many rows for one launch");
+    // gridDim.z is limited to 65535: walk the batch in slabs
+    for (uint64_t b0 = 0; b0 < B; b0 += 65535) {
+        const uint64_t nb = (B - b0) < 65535 ? (B - b0) : 65535;
+        dim3 grid((unsigned)rn_ceil_div(S, kTile), (unsigned)gy, (unsigned)nb);
+        transpose_kernel<<<grid, 256, 0, ctx->stream>>>(src + b0 * R * S, dst + b0 * R * S,
+                                                        (uint32_t)R, (uint32_t)S);
+    }
+    return rn_after_launch(ctx, what);
+}
+
+int rn_nchw_to_nhwc(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t C, uint64_t H,
+                    uint64_t W)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    return transpose_launch(ctx, src, dst, B, C, H * W, "rn_nchw_to_nhwc");
+}
+
+int rn_nhwc_to_nchw(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t C, uint64_t H,
+                    uint64_t W)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    return transpose_launch(ctx, src, dst, B, H * W, C, "rn_nhwc_to_nchw");
+}
+
+int rn_nchw_to_nhwc_pad(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t C,
+                        uint64_t H, uint64_t W, uint64_t Cpad)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    const uint64_t HW = H * W;
+    if (B * HW * Cpad == 0) return RN_OK;
+    RN_REQUIRE(ctx, src && dst && src != dst, "null or aliased tensor");
+    RN_REQUIRE(ctx, Cpad >= C && C >= 1, "Cpad must be >= C >= 1");
+    RN_REQUIRE(ctx, HW < (1ull << 31) && Cpad < (1ull << 31), "dimension too large");
+    if (Cpad == 4 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        const uint64_t pix = B * HW;
+        nchw_to_nhwc4_kernel<<<rn_stream_grid(pix, 256), 256, 0, ctx->stream>>>(
+            src, reinterpret_cast<float4 *>(dst), (uint32_t)C, (uint32_t)HW, pix);
+    } else {
+        const uint64_t total = B * HW * Cpad;
+        nchw_to_nhwc_pad_kernel<<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
+            src, dst, (uint32_t)C, (uint32_t)HW, (uint32_t)Cpad, total);
+    }
+    return rn_after_launch(ctx, "rn_nchw_to_nhwc_pad");
+}
+
+}  // extern "C"

@@ -1,0 +1,567 @@
+/*
+ * rn_model.c -- the network driver, plain C over the C-ABI of rn_hip.h.
+ *
+ * Replaces the reference driver cuda/inference/main.cu:
+ *   createLayer / createResnet152   main.cu:53-89,109-125  -> rn_model_create + set_tensor/load_dir
+ *   layerForward                    main.cu:127-166        -> block_forward
+ *   resnet152Forward                main.cu:168-226        -> rn_model_forward
+ * generalised over the block counts (ResNet-50/101/152) and the batch size.
+ *
+ * Differences that are deliberate (MI355X-first):
+ *   - activations are NHWC inside; the NCHW input image is converted once (to a
+ *     4-channel zero-padded NHWC image the stem contraction reads);
+ *   - no device synchronisation between ops: everything is queued on the
+ *     context's stream (the reference syncs after every launch, nn.cu:14-85);
+ *   - activation buffers are a fixed set of ping-pong arenas sized for the largest
+ *     batch seen, instead of one cached tensor per block (main.cu:141-159): the
+ *     same "second forward allocates nothing" behaviour with ~3x less memory;
+ *   - the unused device-to-host copy of the layer4 activation (main.cu:207) is gone;
+ *   - RN_FWD_FUSED folds batch-norm, ReLU and the residual add into the
+ *     contraction's epilogue; RN_FWD_REFERENCE_OPS launches one kernel per reference
+ *     op in the reference's order (conv, bn in place, relu in place, add into act3,
+ *     relu), which is the parity baseline for the fused path.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rn_hip.h"
+
+#define RN_MAX_KEY 96
+#define RN_CLASSES 1000
+
+typedef struct {
+    char key[RN_MAX_KEY];
+    uint64_t numel;
+    float *dev;
+    int is_set;
+} rn_param;
+
+typedef struct {
+    char name[RN_MAX_KEY];
+    uint64_t cin, cout, k, stride, pad;
+    int w, bn_w, bn_b, bn_m, bn_v; /* indices into params */
+    float *packed;                 /* K-major panel */
+    float *scale, *shift;          /* folded batch-norm */
+} rn_conv;
+
+typedef struct {
+    char name[RN_MAX_KEY];
+    int conv1, conv2, conv3, ds; /* indices into convs; ds = -1 when absent */
+} rn_block;
+
+typedef struct {
+    const char *op;
+    char layer[RN_MAX_KEY];
+    double flops, bytes;
+    rn_event *start, *stop;
+    float ms;
+} rn_prof;
+
+struct rn_model {
+    rn_ctx *ctx;
+    int arch;
+    int depths[4];
+    rn_param *params;
+    uint64_t n_params;
+    rn_conv *convs;
+    int n_convs;
+    rn_block *blocks;
+    int n_blocks;
+    int fc_w, fc_b;
+    int finalized;
+    /* activation arenas, sized for batch_cap images */
+    uint64_t batch_cap;
+    float *x4, *p0, *p1, *dsb, *t1, *t2, *pooled;
+    uint64_t act_bytes;
+    /* profiling */
+    int profiling;
+    rn_prof *prof;
+    uint64_t n_prof, cap_prof;
+};
+
+static const uint64_t kWidths[4][3] = {{64, 64, 256}, {256, 128, 512}, {512, 256, 1024},
+                                       {1024, 512, 2048}};
+static const uint64_t kStrides[4] = {1, 2, 2, 2};
+
+static int add_param(rn_model *m, const char *key, uint64_t numel)
+{
+    rn_param *p = &m->params[m->n_params];
+    snprintf(p->key, RN_MAX_KEY, "%s", key);
+    p->numel = numel;
+    p->dev = NULL;
+    p->is_set = 0;
+    return (int)m->n_params++;
+}
+
+static int add_conv(rn_model *m, const char *name, const char *bn_name, uint64_t cin, uint64_t cout,
+                    uint64_t k, uint64_t stride, uint64_t pad)
+{
+    rn_conv *c = &m->convs[m->n_convs];
+    char key[RN_MAX_KEY + 16];
+    memset(c, 0, sizeof(*c));
+    snprintf(c->name, RN_MAX_KEY, "%s", name);
+    c->cin = cin;
+    c->cout = cout;
+    c->k = k;
+    c->stride = stride;
+    c->pad = pad;
+    snprintf(key, sizeof(key), "%s.weight", name);
+    c->w = add_param(m, key, cout * cin * k * k);
+    snprintf(key, sizeof(key), "%s.weight", bn_name);
+    c->bn_w = add_param(m, key, cout);
+    snprintf(key, sizeof(key), "%s.bias", bn_name);
+    c->bn_b = add_param(m, key, cout);
+    snprintf(key, sizeof(key), "%s.running_mean", bn_name);
+    c->bn_m = add_param(m, key, cout);
+    snprintf(key, sizeof(key), "%s.running_var", bn_name);
+    c->bn_v = add_param(m, key, cout);
+    return m->n_convs++;
+}
+
+int rn_model_create(rn_ctx *ctx, rn_model **out, int arch)
+{
+    static const int d50[4] = {3, 4, 6, 3}, d101[4] = {3, 4, 23, 3}, d152[4] = {3, 8, 36, 3};
+    const int *d;
+    rn_model *m;
+    int li, bi, total_blocks = 0, max_convs;
+    if (!ctx || !out) return RN_ERR_INVALID;
+    *out = NULL;
+    if (arch == 50) d = d50;
+    else if (arch == 101) d = d101;
+    else if (arch == 152) d = d152;
+    else return RN_ERR_UNSUPPORTED;
+    m = (rn_model *)calloc(1, sizeof(rn_model));
+    if (!m) return RN_ERR_NOMEM;
+    m->ctx = ctx;
+    m->arch = arch;
+    for (li = 0; li < 4; ++li) {
+        m->depths[li] = d[li];
+        total_blocks += d[li];
+    }
+    max_convs = 1 + 3 * total_blocks + 4;
+    m->params = (rn_param *)calloc((size_t)max_convs * 5 + 2, sizeof(rn_param));
+    m->convs = (rn_conv *)calloc((size_t)max_convs, sizeof(rn_conv));
+    m->blocks = (rn_block *)calloc((size_t)total_blocks, sizeof(rn_block));
+    if (!m->params || !m->convs || !m->blocks) {
+        rn_model_destroy(m);
+        return RN_ERR_NOMEM;
+    }
+    /* stem: conv1 7x7 s2 p3 + bn1 (main.cu:111-112) */
+    add_conv(m, "conv1", "bn1", 3, 64, 7, 2, 3);
+    for (li = 0; li < 4; ++li) {
+        for (bi = 0; bi < d[li]; ++bi) {
+            rn_block *b = &m->blocks[m->n_blocks++];
+            char pre[RN_MAX_KEY], name[RN_MAX_KEY + 16], bn[RN_MAX_KEY + 16];
+            const uint64_t cin = bi == 0 ? kWidths[li][0] : kWidths[li][2];
+            const uint64_t mid = kWidths[li][1], cout = kWidths[li][2];
+            const uint64_t stride = bi == 0 ? kStrides[li] : 1;
+            snprintf(pre, sizeof(pre), "layer%d.%d", li + 1, bi);
+            snprintf(b->name, RN_MAX_KEY, "%s", pre);
+            b->ds = -1;
+            /* projection shortcut iff block 0 and (stride != 1 or cin != cout): main.cu:71 */
+            if (bi == 0 && (stride != 1 || cin != cout)) {
+                snprintf(name, sizeof(name), "%s.downsample.0", pre);
+                snprintf(bn, sizeof(bn), "%s.downsample.1", pre);
+                b->ds = add_conv(m, name, bn, cin, cout, 1, stride, 0);
+            }
+            snprintf(name, sizeof(name), "%s.conv1", pre);
+            snprintf(bn, sizeof(bn), "%s.bn1", pre);
+            b->conv1 = add_conv(m, name, bn, cin, mid, 1, 1, 0);
+            snprintf(name, sizeof(name), "%s.conv2", pre);
+            snprintf(bn, sizeof(bn), "%s.bn2", pre);
+            b->conv2 = add_conv(m, name, bn, mid, mid, 3, stride, 1); /* stride on the 3x3 */
+            snprintf(name, sizeof(name), "%s.conv3", pre);
+            snprintf(bn, sizeof(bn), "%s.bn3", pre);
+            b->conv3 = add_conv(m, name, bn, mid, cout, 1, 1, 0);
+        }
+    }
+    m->fc_w = add_param(m, "fc.weight", (uint64_t)RN_CLASSES * 2048);
+    m->fc_b = add_param(m, "fc.bias", RN_CLASSES);
+    *out = m;
+    return RN_OK;
+}
+
+static void free_acts(rn_model *m)
+{
+    float **bufs[7];
+    int i;
+    bufs[0] = &m->x4; bufs[1] = &m->p0; bufs[2] = &m->p1; bufs[3] = &m->dsb;
+    bufs[4] = &m->t1; bufs[5] = &m->t2; bufs[6] = &m->pooled;
+    for (i = 0; i < 7; ++i) {
+        if (*bufs[i]) rn_free(m->ctx, *bufs[i]);
+        *bufs[i] = NULL;
+    }
+    m->batch_cap = 0;
+    m->act_bytes = 0;
+}
+
+static void free_prof(rn_model *m)
+{
+    uint64_t i;
+    for (i = 0; i < m->cap_prof; ++i) {
+        rn_event_destroy(m->prof[i].start);
+        rn_event_destroy(m->prof[i].stop);
+    }
+    free(m->prof);
+    m->prof = NULL;
+    m->n_prof = m->cap_prof = 0;
+}
+
+int rn_model_destroy(rn_model *m)
+{
+    uint64_t i;
+    int c;
+    if (!m) return RN_OK;
+    if (m->ctx) rn_sync(m->ctx);
+    if (m->params) {
+        for (i = 0; i < m->n_params; ++i) rn_free(m->ctx, m->params[i].dev);
+    }
+    if (m->convs) {
+        for (c = 0; c < m->n_convs; ++c) {
+            rn_free(m->ctx, m->convs[c].packed);
+            rn_free(m->ctx, m->convs[c].scale);
+            rn_free(m->ctx, m->convs[c].shift);
+        }
+    }
+    free_acts(m);
+    free_prof(m);
+    free(m->params);
+    free(m->convs);
+    free(m->blocks);
+    free(m);
+    return RN_OK;
+}
+
+const char *rn_model_tensor_key(const rn_model *m, uint64_t index, uint64_t *numel)
+{
+    if (!m || index >= m->n_params) return NULL;
+    if (numel) *numel = m->params[index].numel;
+    return m->params[index].key;
+}
+
+int rn_model_set_tensor(rn_model *m, const char *key, const float *host_data, uint64_t numel)
+{
+    uint64_t i;
+    if (!m || !key || !host_data) return RN_ERR_INVALID;
+    for (i = 0; i < m->n_params; ++i) {
+        rn_param *p = &m->params[i];
+        if (strcmp(p->key, key) != 0) continue;
+        if (p->numel != numel) return RN_ERR_INVALID;
+        if (!p->dev) {
+            int st = rn_malloc(m->ctx, (void **)&p->dev, numel * sizeof(float));
+            if (st != RN_OK) return st;
+        }
+        p->is_set = 1;
+        m->finalized = 0;
+        return rn_memcpy_h2d(m->ctx, p->dev, host_data, numel * sizeof(float));
+    }
+    return RN_ERR_INVALID; /* unknown key (e.g. *.num_batches_tracked): callers skip those */
+}
+
+int rn_model_load_dir(rn_model *m, const char *weights_dir)
+{
+    uint64_t i;
+    if (!m || !weights_dir) return RN_ERR_INVALID;
+    for (i = 0; i < m->n_params; ++i) {
+        rn_param *p = &m->params[i];
+        char path[1024];
+        float *dev = NULL;
+        uint64_t n = 0;
+        int st;
+        snprintf(path, sizeof(path), "%s/%s", weights_dir, p->key);
+        st = rn_load_f32_file(m->ctx, path, &dev, &n);
+        if (st != RN_OK) return st;
+        if (n != p->numel) {
+            rn_free(m->ctx, dev);
+            return RN_ERR_INVALID;
+        }
+        if (p->dev) rn_free(m->ctx, p->dev);
+        p->dev = dev;
+        p->is_set = 1;
+    }
+    m->finalized = 0;
+    return RN_OK;
+}
+
+int rn_model_finalize(rn_model *m)
+{
+    uint64_t i;
+    int c, st;
+    if (!m) return RN_ERR_INVALID;
+    for (i = 0; i < m->n_params; ++i) {
+        if (!m->params[i].is_set) return RN_ERR_INVALID;
+    }
+    for (c = 0; c < m->n_convs; ++c) {
+        rn_conv *cv = &m->convs[c];
+        const uint64_t pn = rn_conv2d_packed_weight_numel(cv->cin, cv->cout, cv->k);
+        if (!cv->packed) {
+            st = rn_malloc(m->ctx, (void **)&cv->packed, pn * sizeof(float));
+            if (st != RN_OK) return st;
+            st = rn_malloc(m->ctx, (void **)&cv->scale, cv->cout * sizeof(float));
+            if (st != RN_OK) return st;
+            st = rn_malloc(m->ctx, (void **)&cv->shift, cv->cout * sizeof(float));
+            if (st != RN_OK) return st;
+        }
+        st = rn_conv2d_pack_weight(m->ctx, m->params[cv->w].dev, cv->packed, cv->cin, cv->cout,
+                                   cv->k);
+        if (st != RN_OK) return st;
+        st = rn_batchnorm2d_fold(m->ctx, m->params[cv->bn_w].dev, m->params[cv->bn_b].dev,
+                                 m->params[cv->bn_m].dev, m->params[cv->bn_v].dev, cv->scale,
+                                 cv->shift, cv->cout);
+        if (st != RN_OK) return st;
+    }
+    st = rn_sync(m->ctx);
+    if (st != RN_OK) return st;
+    m->finalized = 1;
+    return RN_OK;
+}
+
+/* per-image element counts of the arenas (see the header comment) */
+#define X4_PER_IMG ((uint64_t)224 * 224 * 4)
+#define P_PER_IMG ((uint64_t)56 * 56 * 256) /* == 112*112*64, the stem output */
+#define T_PER_IMG ((uint64_t)56 * 56 * 128) /* layer2.0 conv1 output, the largest mid tensor */
+
+static int ensure_acts(rn_model *m, uint64_t B)
+{
+    int st;
+    if (B <= m->batch_cap) return RN_OK;
+    free_acts(m);
+    st = rn_malloc(m->ctx, (void **)&m->x4, B * X4_PER_IMG * sizeof(float));
+    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->p0, B * P_PER_IMG * sizeof(float));
+    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->p1, B * P_PER_IMG * sizeof(float));
+    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->dsb, B * P_PER_IMG * sizeof(float));
+    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->t1, B * T_PER_IMG * sizeof(float));
+    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->t2, B * T_PER_IMG * sizeof(float));
+    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->pooled, B * 2048 * sizeof(float));
+    if (st != RN_OK) {
+        free_acts(m);
+        return st;
+    }
+    m->batch_cap = B;
+    m->act_bytes = B * (X4_PER_IMG + 3 * P_PER_IMG + 2 * T_PER_IMG + 2048) * sizeof(float);
+    return RN_OK;
+}
+
+uint64_t rn_model_activation_bytes(const rn_model *m) { return m ? m->act_bytes : 0; }
+
+/* ---- profiling --------------------------------------------------------- */
+static int prof_begin(rn_model *m, const char *op, const char *layer, double flops, double bytes)
+{
+    rn_prof *r;
+    if (!m->profiling) return RN_OK;
+    if (m->n_prof == m->cap_prof) {
+        const uint64_t ncap = m->cap_prof ? m->cap_prof * 2 : 256;
+        rn_prof *np = (rn_prof *)realloc(m->prof, ncap * sizeof(rn_prof));
+        uint64_t i;
+        if (!np) return RN_ERR_NOMEM;
+        m->prof = np;
+        for (i = m->cap_prof; i < ncap; ++i) {
+            int st;
+            memset(&np[i], 0, sizeof(rn_prof));
+            st = rn_event_create(m->ctx, &np[i].start);
+            if (st == RN_OK) st = rn_event_create(m->ctx, &np[i].stop);
+            if (st != RN_OK) {
+                m->cap_prof = i;
+                return st;
+            }
+        }
+        m->cap_prof = ncap;
+    }
+    r = &m->prof[m->n_prof];
+    r->op = op;
+    snprintf(r->layer, RN_MAX_KEY, "%s", layer);
+    r->flops = flops;
+    r->bytes = bytes;
+    r->ms = -1.f;
+    return rn_event_record(m->ctx, r->start);
+}
+
+static int prof_end(rn_model *m)
+{
+    if (!m->profiling) return RN_OK;
+    return rn_event_record(m->ctx, m->prof[m->n_prof++].stop);
+}
+
+int rn_model_set_profiling(rn_model *m, int on)
+{
+    if (!m) return RN_ERR_INVALID;
+    m->profiling = on ? 1 : 0;
+    return RN_OK;
+}
+
+uint64_t rn_model_profile_count(const rn_model *m) { return m ? m->n_prof : 0; }
+
+int rn_model_profile_get(const rn_model *m, uint64_t index, const char **op_name,
+                         const char **layer_name, float *ms, double *flops, double *bytes)
+{
+    rn_prof *r;
+    if (!m || index >= m->n_prof) return RN_ERR_INVALID;
+    r = &m->prof[index];
+    if (r->ms < 0.f) {
+        int st = rn_event_elapsed_ms(r->start, r->stop, &r->ms);
+        if (st != RN_OK) return st;
+    }
+    if (op_name) *op_name = r->op;
+    if (layer_name) *layer_name = r->layer;
+    if (ms) *ms = r->ms;
+    if (flops) *flops = r->flops;
+    if (bytes) *bytes = r->bytes;
+    return RN_OK;
+}
+
+#define TRY(expr)                   \
+    do {                            \
+        int st_ = (expr);           \
+        if (st_ != RN_OK) return st_; \
+    } while (0)
+
+/* ---- ops with profiling brackets --------------------------------------- */
+static int op_conv(rn_model *m, const rn_conv *cv, const float *x, float *y, uint64_t B,
+                   uint64_t H, uint64_t W, const rn_epilogue *ep)
+{
+    const uint64_t ho = rn_conv_output_size(H, cv->k, cv->stride, cv->pad);
+    const uint64_t wo = rn_conv_output_size(W, cv->k, cv->stride, cv->pad);
+    const double M = (double)(B * ho * wo), K = (double)(cv->cin * cv->k * cv->k);
+    double bytes = 4.0 * ((double)(B * H * W * cv->cin) + K * (double)cv->cout +
+                          M * (double)cv->cout);
+    if (ep && ep->residual) bytes += 4.0 * M * (double)cv->cout;
+    TRY(prof_begin(m, ep ? "conv2d+epilogue" : "conv2d", cv->name, 2.0 * M * (double)cv->cout * K,
+                   bytes));
+    TRY(rn_conv2d_nhwc_forward(m->ctx, x, y, cv->packed, cv->k, cv->stride, cv->pad, ho, wo, B,
+                               cv->cin, cv->cout, H, W, ep));
+    return prof_end(m);
+}
+
+static int op_bn(rn_model *m, const rn_conv *cv, float *y, uint64_t B, uint64_t HW)
+{
+    const double n = (double)(B * cv->cout * HW);
+    TRY(prof_begin(m, "batchnorm2d", cv->name, 0.0, 8.0 * n + 16.0 * (double)cv->cout));
+    TRY(rn_batchnorm2d_forward(m->ctx, y, y, m->params[cv->bn_w].dev, m->params[cv->bn_b].dev,
+                               m->params[cv->bn_m].dev, m->params[cv->bn_v].dev, B, cv->cout, HW));
+    return prof_end(m);
+}
+
+static int op_relu(rn_model *m, const char *layer, float *y, uint64_t n)
+{
+    TRY(prof_begin(m, "relu", layer, 0.0, 8.0 * (double)n));
+    TRY(rn_relu_forward(m->ctx, y, y, n));
+    return prof_end(m);
+}
+
+static int op_add(rn_model *m, const char *layer, float *y, const float *shortcut, uint64_t n)
+{
+    TRY(prof_begin(m, "add", layer, 0.0, 12.0 * (double)n));
+    TRY(rn_add_forward(m->ctx, y, shortcut, y, n)); /* out aliases inp1: main.cu:162 */
+    return prof_end(m);
+}
+
+/* one bottleneck block (layerForward body, main.cu:131-164).  x -> y, both NHWC. */
+static int block_forward(rn_model *m, const rn_block *b, const float *x, float *y, uint64_t B,
+                         uint64_t *H, uint64_t *W, int mode)
+{
+    const rn_conv *c1 = &m->convs[b->conv1], *c2 = &m->convs[b->conv2], *c3 = &m->convs[b->conv3];
+    const uint64_t h = *H, w = *W;
+    const uint64_t ho = rn_conv_output_size(h, c2->k, c2->stride, c2->pad);
+    const uint64_t wo = rn_conv_output_size(w, c2->k, c2->stride, c2->pad);
+    const float *shortcut = x;
+    if (mode == RN_FWD_FUSED) {
+        rn_epilogue ep;
+        if (b->ds >= 0) {
+            const rn_conv *cd = &m->convs[b->ds];
+            ep.scale = cd->scale; ep.shift = cd->shift; ep.residual = NULL; ep.relu = 0;
+            TRY(op_conv(m, cd, x, m->dsb, B, h, w, &ep));
+            shortcut = m->dsb;
+        }
+        ep.scale = c1->scale; ep.shift = c1->shift; ep.residual = NULL; ep.relu = 1;
+        TRY(op_conv(m, c1, x, m->t1, B, h, w, &ep));
+        ep.scale = c2->scale; ep.shift = c2->shift;
+        TRY(op_conv(m, c2, m->t1, m->t2, B, h, w, &ep));
+        ep.scale = c3->scale; ep.shift = c3->shift; ep.residual = shortcut;
+        TRY(op_conv(m, c3, m->t2, y, B, ho, wo, &ep));
+    } else {
+        if (b->ds >= 0) {
+            const rn_conv *cd = &m->convs[b->ds];
+            TRY(op_conv(m, cd, x, m->dsb, B, h, w, NULL));
+            TRY(op_bn(m, cd, m->dsb, B, ho * wo));
+            shortcut = m->dsb;
+        }
+        TRY(op_conv(m, c1, x, m->t1, B, h, w, NULL));
+        TRY(op_bn(m, c1, m->t1, B, h * w));
+        TRY(op_relu(m, c1->name, m->t1, B * h * w * c1->cout));
+        TRY(op_conv(m, c2, m->t1, m->t2, B, h, w, NULL));
+        TRY(op_bn(m, c2, m->t2, B, ho * wo));
+        TRY(op_relu(m, c2->name, m->t2, B * ho * wo * c2->cout));
+        TRY(op_conv(m, c3, m->t2, y, B, ho, wo, NULL));
+        TRY(op_bn(m, c3, y, B, ho * wo));
+        TRY(op_add(m, b->name, y, shortcut, B * ho * wo * c3->cout));
+        TRY(op_relu(m, b->name, y, B * ho * wo * c3->cout));
+    }
+    *H = ho;
+    *W = wo;
+    return RN_OK;
+}
+
+int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
+{
+    const rn_conv *stem;
+    uint64_t H = 224, W = 224, ho, wo, ph, pw;
+    float *x, *y, *tmp;
+    int bi, saved_layout, st;
+    if (!m || !input_nchw || !logits || B == 0) return RN_ERR_INVALID;
+    if (mode != RN_FWD_REFERENCE_OPS && mode != RN_FWD_FUSED) return RN_ERR_INVALID;
+    if (!m->finalized) return RN_ERR_INVALID;
+    TRY(ensure_acts(m, B));
+    m->n_prof = 0;
+    saved_layout = rn_ctx_get_layout(m->ctx);
+    rn_ctx_set_layout(m->ctx, RN_LAYOUT_NHWC);
+    st = RN_OK;
+    do {
+#define STEP(expr) if ((st = (expr)) != RN_OK) break
+        stem = &m->convs[0];
+        STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0, 4.0 * (double)(B * 224 * 224 * 7)));
+        STEP(rn_nchw_to_nhwc_pad(m->ctx, input_nchw, m->x4, B, 3, H, W, 4));
+        STEP(prof_end(m));
+        ho = rn_conv_output_size(H, stem->k, stem->stride, stem->pad);
+        wo = rn_conv_output_size(W, stem->k, stem->stride, stem->pad);
+        if (mode == RN_FWD_FUSED) {
+            rn_epilogue ep;
+            ep.scale = stem->scale; ep.shift = stem->shift; ep.residual = NULL; ep.relu = 1;
+            STEP(op_conv(m, stem, m->x4, m->p1, B, H, W, &ep));
+        } else {
+            STEP(op_conv(m, stem, m->x4, m->p1, B, H, W, NULL));
+            STEP(op_bn(m, stem, m->p1, B, ho * wo));
+            STEP(op_relu(m, "conv1", m->p1, B * ho * wo * 64));
+        }
+        /* maxpool 3x3 s2 p1 (main.cu:114,192) */
+        ph = rn_conv_output_size(ho, 3, 2, 1);
+        pw = rn_conv_output_size(wo, 3, 2, 1);
+        STEP(prof_begin(m, "maxpool2d", "maxpool", 0.0,
+                        4.0 * (double)(B * 64 * (ho * wo + ph * pw))));
+        STEP(rn_maxpool2d_forward(m->ctx, m->p1, m->p0, 3, 2, 1, ph, pw, B, 64, ho, wo));
+        STEP(prof_end(m));
+        H = ph;
+        W = pw;
+        x = m->p0;
+        y = m->p1;
+        for (bi = 0; bi < m->n_blocks; ++bi) {
+            STEP(block_forward(m, &m->blocks[bi], x, y, B, &H, &W, mode));
+            tmp = x; x = y; y = tmp;
+        }
+        if (st != RN_OK) break;
+        /* global 7x7 average (main.cu:120,213) then fc (main.cu:122,224) */
+        STEP(prof_begin(m, "avgpool2d", "avgpool", 0.0, 4.0 * (double)(B * 2048 * (H * W + 1))));
+        STEP(rn_avgpool2d_forward(m->ctx, x, m->pooled, 7, 1, 0, rn_conv_output_size(H, 7, 1, 0),
+                                  rn_conv_output_size(W, 7, 1, 0), B, 2048, H, W));
+        STEP(prof_end(m));
+        STEP(prof_begin(m, "linear", "fc", 2.0 * (double)B * 2048.0 * RN_CLASSES,
+                        4.0 * ((double)B * 2048.0 + 2048.0 * RN_CLASSES + RN_CLASSES +
+                               (double)B * RN_CLASSES)));
+        STEP(rn_linear_forward(m->ctx, m->pooled, logits, m->params[m->fc_w].dev,
+                               m->params[m->fc_b].dev, B, 2048, RN_CLASSES));
+        STEP(prof_end(m));
+#undef STEP
+    } while (0);
+    rn_ctx_set_layout(m->ctx, saved_layout);
+    return st;
+}

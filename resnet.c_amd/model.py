@@ -1,0 +1,284 @@
+"""The model graph, twice.
+
+``ResnetModel`` / ``createResnet`` / ``resnetForward`` mirror the reference
+driver cuda/inference/main.cu:7-226 object for object on top of the nn layer
+wrappers (one C-ABI call per reference op, NCHW tensors, lazily cached
+activations) -- the literal drop-in for code written against ops/nn/tensor.
+
+``NativeModel`` wraps the plain-C driver inside librn_hip.so (rn_model.c): NHWC
+engine layout, packed weights, optional fused epilogues, no Python in the loop.
+It is what bench.py times.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from . import nn, weights
+from .tensor import Context, Device, FloatTensor, Shape, get_ctx
+
+ARCH_ID = {"resnet50": 50, "resnet101": 101, "resnet152": 152}
+
+
+# ---------------------------------------------------------------------------
+# reference-shaped graph (main.cu)
+# ---------------------------------------------------------------------------
+class Downsample:  # main.cu:7-16
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d):
+        self.conv, self.bn = conv, bn
+        self.act = FloatTensor(Device.GPU)
+
+
+class ResnetBlock:  # main.cu:18-46
+    def __init__(self, conv1, bn1, conv2, bn2, conv3, bn3, downsample: Optional[Downsample],
+                 in_channels, inter_channels, out_channels, stride):
+        self.conv1, self.bn1 = conv1, bn1
+        self.conv2, self.bn2 = conv2, bn2
+        self.conv3, self.bn3 = conv3, bn3
+        self.downsample = downsample
+        self.in_channels, self.inter_channels = in_channels, inter_channels
+        self.out_channels, self.stride = out_channels, stride
+        self.act1_out = FloatTensor(Device.GPU)
+        self.act2_out = FloatTensor(Device.GPU)
+        self.act3_out = FloatTensor(Device.GPU)
+
+
+class Layer:  # main.cu:48-51
+    def __init__(self, blocks: List[ResnetBlock]):
+        self.blocks = blocks
+
+
+class _Loader:
+    """Where layer weights come from: a weights_bin/ directory (the reference's only
+    source, nn.cuh:18-25) or an in-memory state dict."""
+
+    def __init__(self, state: Optional[Dict[str, np.ndarray]] = None):
+        self.state = state
+
+    def tensor(self, key: str, shape) -> FloatTensor:
+        if self.state is None:
+            return FloatTensor.loadToCuda(nn.WEIGHTS_DIR + key).view(Shape(shape))
+        return FloatTensor.from_numpy(self.state[key], Device.GPU).view(Shape(shape))
+
+    def conv(self, name, cin, cout, k, stride=1, padding=0) -> nn.Conv2d:
+        return nn.Conv2d(self.tensor(name + ".weight", (cout, cin, k, k)), cin, cout, k, stride,
+                         padding)
+
+    def bn(self, name, c) -> nn.BatchNorm2d:
+        return nn.BatchNorm2d(*(self.tensor(f"{name}.{f}", (c,)) for f in weights.BN_FIELDS), c)
+
+    def linear(self, name, fin, fout) -> nn.Linear:
+        return nn.Linear(self.tensor(name + ".weight", (fout, fin)),
+                         self.tensor(name + ".bias", (fout,)), fin, fout)
+
+
+def createLayer(ld: _Loader, layer_id: int, in_channels: int, inter_channels: int,
+                out_channels: int, n_blocks: int, stride: int = 1) -> Layer:
+    """main.cu:53-89."""
+
+    def load_block(block_id, cin, mid, cout, s) -> ResnetBlock:
+        pre = f"layer{layer_id}.{block_id}."
+        ds = None
+        if block_id == 0 and (s != 1 or cin != cout):  # main.cu:71
+            ds = Downsample(ld.conv(pre + "downsample.0", cin, cout, 1, s),
+                            ld.bn(pre + "downsample.1", cout))
+        return ResnetBlock(ld.conv(pre + "conv1", cin, mid, 1), ld.bn(pre + "bn1", mid),
+                           ld.conv(pre + "conv2", mid, mid, 3, s, 1), ld.bn(pre + "bn2", mid),
+                           ld.conv(pre + "conv3", mid, cout, 1), ld.bn(pre + "bn3", cout),
+                           ds, cin, mid, cout, s)
+
+    blocks = [load_block(0, in_channels, inter_channels, out_channels, stride)]
+    for i in range(1, n_blocks):
+        blocks.append(load_block(i, out_channels, inter_channels, out_channels, 1))
+    return Layer(blocks)
+
+
+class ResnetModel:  # main.cu:91-107
+    def __init__(self, ld: _Loader, arch: str):
+        d = weights.depths_of(arch)
+        self.arch = arch
+        self.conv1 = ld.conv("conv1", 3, 64, 7, 2, 3)
+        self.bn1 = ld.bn("bn1", 64)
+        self.act1_out = FloatTensor(Device.GPU)
+        self.maxpool = nn.Pool2d(64, 3, 2, 1)
+        self.maxpool_out = FloatTensor(Device.GPU)
+        self.layer1 = createLayer(ld, 1, 64, 64, 256, d[0])
+        self.layer2 = createLayer(ld, 2, 256, 128, 512, d[1], 2)
+        self.layer3 = createLayer(ld, 3, 512, 256, 1024, d[2], 2)
+        self.layer4 = createLayer(ld, 4, 1024, 512, 2048, d[3], 2)
+        self.avgpool = nn.Pool2d(2048, 7)
+        self.avgpool_out = FloatTensor(Device.GPU)
+        self.fc = ld.linear("fc", 2048, 1000)
+        self.fc_out = FloatTensor(Device.GPU)
+
+
+def createResnet(arch: str = "resnet152", state: Optional[Dict[str, np.ndarray]] = None):
+    """createResnet152 (main.cu:109-125) for any depth; weights from ``weights_bin/``
+    (state=None, like the reference) or from a dict."""
+    return ResnetModel(_Loader(state), arch)
+
+
+def createResnet152(state=None) -> ResnetModel:
+    return createResnet("resnet152", state)
+
+
+def _ensure(holder, attr: str, shape: Shape) -> FloatTensor:
+    """`if (!act) act = FloatTensor(shape, GPU)` (main.cu:141-143 and friends)."""
+    t = getattr(holder, attr)
+    if not t or t.shape() != shape:
+        t = FloatTensor(shape, Device.GPU)
+        setattr(holder, attr, t)
+    return t
+
+
+def layerForward(layer: Layer, x: FloatTensor) -> FloatTensor:
+    """main.cu:127-166."""
+    y = x
+    for block in layer.blocks:
+        if block.downsample:
+            ds = block.downsample
+            _ensure(ds, "act", ds.conv.getOutShape(y.shape()))
+            ds.conv.forward(y, ds.act)
+            ds.bn.forward(ds.act, ds.act)
+        _ensure(block, "act1_out", block.conv1.getOutShape(y.shape()))
+        block.conv1.forward(y, block.act1_out)
+        block.bn1.forward(block.act1_out, block.act1_out)
+        nn.reluForward(block.act1_out, block.act1_out)
+
+        _ensure(block, "act2_out", block.conv2.getOutShape(block.act1_out.shape()))
+        block.conv2.forward(block.act1_out, block.act2_out)
+        block.bn2.forward(block.act2_out, block.act2_out)
+        nn.reluForward(block.act2_out, block.act2_out)
+
+        _ensure(block, "act3_out", block.conv3.getOutShape(block.act2_out.shape()))
+        block.conv3.forward(block.act2_out, block.act3_out)
+        block.bn3.forward(block.act3_out, block.act3_out)
+        nn.addForward(block.act3_out, block.downsample.act if block.downsample else y,
+                      block.act3_out)
+        nn.reluForward(block.act3_out, block.act3_out)
+        y = block.act3_out
+    return y
+
+
+def resnetForward(model: ResnetModel, x: FloatTensor) -> FloatTensor:
+    """resnet152Forward (main.cu:168-226) without the progress prints and without the
+    unused D2H copy of the layer4 activation (main.cu:207).  Returns model.fc_out."""
+    assert x.device == Device.GPU
+    x.shape().as_tuple(4)
+    conv1_out_shape = model.conv1.getOutShape(x.shape())
+    _ensure(model, "act1_out", conv1_out_shape)
+    model.conv1.forward(x, model.act1_out)
+    model.bn1.forward(model.act1_out, model.act1_out)
+    nn.reluForward(model.act1_out, model.act1_out)
+    _ensure(model, "maxpool_out", model.maxpool.getOutShape(conv1_out_shape))
+    model.maxpool.maxforward(model.act1_out, model.maxpool_out)
+    y = layerForward(model.layer1, model.maxpool_out)
+    y = layerForward(model.layer2, y)
+    y = layerForward(model.layer3, y)
+    y = layerForward(model.layer4, y)
+    _ensure(model, "avgpool_out", model.avgpool.getOutShape(y.shape()))
+    model.avgpool.avgforward(y, model.avgpool_out)
+    s = model.avgpool_out.shape()
+    flat = model.avgpool_out.view(Shape((s[0], s[1] * s[2] * s[3])))
+    _ensure(model, "fc_out", Shape((flat.shape()[0], model.fc.out_features)))
+    model.fc.forward(flat, model.fc_out)
+    return model.fc_out
+
+
+def argmax(logits: np.ndarray) -> np.ndarray:
+    """Host argmax of main.cu:243-251: strict '<', first maximum wins."""
+    out = np.zeros(logits.shape[0], dtype=np.int64)
+    for b in range(logits.shape[0]):
+        mx = 0
+        row = logits[b]
+        for i in range(1, row.shape[0]):
+            if row[mx] < row[i]:
+                mx = i
+        out[b] = mx
+    return out
+
+
+# ---------------------------------------------------------------------------
+# the C driver
+# ---------------------------------------------------------------------------
+class NativeModel:
+    def __init__(self, arch: str = "resnet50", state: Optional[Dict[str, np.ndarray]] = None,
+                 weights_dir: Optional[str] = None, ctx: Optional[Context] = None):
+        self.ctx = ctx or get_ctx()
+        self.arch = arch
+        lib = L.lib()
+        h = ctypes.c_void_p()
+        L.check(lib.rn_model_create(self.ctx.handle, ctypes.byref(h), ARCH_ID[arch]),
+                "rn_model_create", self.ctx.handle)
+        self.handle = h
+        if (state is None) == (weights_dir is None):
+            raise ValueError("give exactly one of state / weights_dir")
+        if weights_dir is not None:
+            L.check(lib.rn_model_load_dir(h, weights_dir.encode()), "rn_model_load_dir",
+                    self.ctx.handle)
+        else:
+            for key, numel in self.tensor_keys():
+                arr = np.ascontiguousarray(state[key], dtype=np.float32)
+                assert arr.size == numel, (key, arr.size, numel)
+                L.check(lib.rn_model_set_tensor(h, key.encode(), arr.ctypes.data, numel),
+                        f"rn_model_set_tensor({key})", self.ctx.handle)
+        L.check(lib.rn_model_finalize(h), "rn_model_finalize", self.ctx.handle)
+
+    def tensor_keys(self) -> List[Tuple[str, int]]:
+        out, i, n = [], 0, ctypes.c_uint64()
+        while True:
+            k = L.lib().rn_model_tensor_key(self.handle, i, ctypes.byref(n))
+            if k is None:
+                return out
+            out.append((k.decode(), n.value))
+            i += 1
+
+    def forward_ptr(self, input_ptr: int, B: int, logits_ptr: int, fused: bool = True) -> None:
+        """Queue one forward on the context's stream (asynchronous)."""
+        L.check(L.lib().rn_model_forward(self.handle, input_ptr, B, logits_ptr,
+                                         L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS),
+                "rn_model_forward", self.ctx.handle)
+
+    def forward(self, x: np.ndarray, fused: bool = True) -> np.ndarray:
+        """NCHW host array -> logits host array (synchronous convenience)."""
+        xin = FloatTensor.from_numpy(x, Device.GPU)
+        B = x.shape[0]
+        out = FloatTensor((B, 1000), Device.GPU)
+        self.forward_ptr(xin.data(), B, out.data(), fused)
+        self.ctx.sync()
+        return out.numpy()
+
+    def set_profiling(self, on: bool) -> None:
+        L.check(L.lib().rn_model_set_profiling(self.handle, int(on)), "rn_model_set_profiling")
+
+    def profile(self) -> List[dict]:
+        """Per-op records of the last profiled forward (after a sync)."""
+        lib = L.lib()
+        self.ctx.sync()
+        recs = []
+        op, layer = ctypes.c_char_p(), ctypes.c_char_p()
+        ms, fl, by = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
+        for i in range(lib.rn_model_profile_count(self.handle)):
+            L.check(lib.rn_model_profile_get(self.handle, i, ctypes.byref(op), ctypes.byref(layer),
+                                             ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by)),
+                    "rn_model_profile_get")
+            recs.append({"op": op.value.decode(), "layer": layer.value.decode(), "ms": ms.value,
+                         "flops": fl.value, "bytes": by.value})
+        return recs
+
+    def activation_bytes(self) -> int:
+        return int(L.lib().rn_model_activation_bytes(self.handle))
+
+    def close(self) -> None:
+        if self.handle:
+            L.lib().rn_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

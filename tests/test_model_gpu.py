@@ -1,0 +1,156 @@
+"""Whole-network parity on the GPU (configs 2, 3 and 5 of BASELINE.md).
+
+The north star's bar: logits within 1e-4 (fp32) of the reference's PyTorch module
+on the same exported weights and test image, top-1 identical.  Golden logits come
+from the reference module itself (tests/golden/make_golden.py).
+"""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import resnet_c_amd as R
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def model50(state50):
+    m = R.NativeModel("resnet50", state=state50)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_resnet50_b1_logits_vs_reference_golden(model50, finch, golden_dir, fused):
+    got = model50.forward(finch, fused=fused)
+    want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
+    want64 = np.load(os.path.join(golden_dir, "resnet50_finch_logits_f64.npy"))
+    assert got.shape == (1, 1000)
+    assert np.abs(got - want).max() <= TOL
+    assert np.abs(got - want64).max() <= TOL
+    assert R.ops.argmax(got)[0] == int(want.argmax(1)[0]) == 112
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_resnet152_b1_logits_vs_reference_golden(state152, finch, golden_dir, fused):
+    m = R.NativeModel("resnet152", state=state152)
+    try:
+        got = m.forward(finch, fused=fused)
+    finally:
+        m.close()
+    want = np.load(os.path.join(golden_dir, "resnet152_finch_logits.npy"))
+    info = json.load(open(os.path.join(golden_dir, "resnet152_taps.json")))
+    assert np.abs(got - want).max() <= TOL
+    assert R.ops.argmax(got)[0] == info["finch_top1"]
+
+
+def test_resnet50_random_pair_vs_golden_and_oracle(model50, state50, golden_dir):
+    x = R.weights.generate_input(2, seed=7)
+    want = np.load(os.path.join(golden_dir, "resnet50_rand2_logits.npy"))
+    for fused in (False, True):
+        got = model50.forward(x, fused=fused)
+        assert np.abs(got - want).max() <= TOL
+        assert np.array_equal(R.ops.argmax(got), want.argmax(1))
+    cpu = O.resnet_forward(state50, x, "resnet50")
+    assert np.abs(model50.forward(x, fused=False) - cpu).max() <= TOL
+
+
+def test_batch_invariance_is_bit_exact(model50, finch):
+    """No op reduces across the batch: row i of a batch equals the
+    batch-1 result of image i bit for bit, whatever the tile the row lands in."""
+    x = R.weights.generate_input(5, seed=11)
+    x[3] = finch[0]
+    for fused in (False, True):
+        full = model50.forward(x, fused=fused)
+        for i in (0, 3, 4):
+            assert np.array_equal(full[i:i + 1], model50.forward(x[i:i + 1], fused=fused))
+        assert np.array_equal(full, model50.forward(x, fused=fused))  # deterministic
+
+
+def test_fused_and_reference_op_sequence_agree(model50):
+    x = R.weights.generate_input(3, seed=21)
+    a, b = model50.forward(x, fused=False), model50.forward(x, fused=True)
+    assert np.abs(a - b).max() <= 2e-5
+    assert np.array_equal(a.argmax(1), b.argmax(1))
+
+
+def test_profile_accounts_for_every_reference_op(model50, finch):
+    model50.set_profiling(True)
+    try:
+        model50.forward(finch, fused=False)
+        recs = model50.profile()
+    finally:
+        model50.set_profiling(False)
+    count = lambda op: sum(r["op"] == op for r in recs)
+    # 53 conv + 53 BN + 49 ReLU + 16 add + maxpool + avgpool + fc = 174
+    assert (count("conv2d"), count("batchnorm2d"), count("relu"), count("add")) == (53, 53, 49, 16)
+    assert count("maxpool2d") == count("avgpool2d") == count("linear") == 1
+    flops = sum(r["flops"] for r in recs)
+    assert abs(flops - 8.178368512e9) < 1.0  # BASELINE.md section 2, per image
+    by = lambda op: sum(r["bytes"] for r in recs if r["op"] == op)
+    assert abs(by("relu") - 76.87e6) < 0.05e6 and abs(by("add") - 66.23e6) < 0.05e6
+    assert abs(by("batchnorm2d") - 88.91e6) < 0.6e6
+    assert all(r["ms"] >= 0 for r in recs)
+
+
+def test_reference_shaped_python_graph_nchw(state50, finch, golden_dir):
+    """createResnet / resnetForward: the reference driver object for object, one
+    C-ABI call per reference op on NCHW tensors (the literal drop-in boundary)."""
+    m = R.createResnet("resnet50", state50)
+    x = R.FloatTensor.from_numpy(finch, R.Device.GPU)
+    out = R.resnetForward(m, x)
+    R.get_ctx().sync()
+    got = out.numpy()
+    want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
+    assert np.abs(got - want).max() <= TOL
+    first_buf = m.layer1.blocks[0].act1_out.data()
+    R.resnetForward(m, x)  # second forward allocates nothing (main.cu:141-159)
+    assert m.layer1.blocks[0].act1_out.data() == first_buf
+    assert m.layer1.blocks[0].downsample is not None and m.layer1.blocks[1].downsample is None
+    assert R.model.argmax(got)[0] == 112
+
+
+def test_plain_c_driver_and_weights_bin_loader(state50, finch, tmp_path):
+    """rn_infer is plain C over the C-ABI: weights_bin/ directory in, 'max index is N' out
+    (the reference's main(), cuda/inference/main.cu:228-254)."""
+    wdir = tmp_path / "weights_bin"
+    R.weights.save_weights_bin(state50, str(wdir))
+    np.zeros(1, np.float32).tofile(wdir / "bn1.num_batches_tracked")  # ignored, like the reference
+    inp = tmp_path / "ILSVRC2012_val_00004749.bin"
+    finch.tofile(inp)
+    exe = os.path.join(os.path.dirname(R._lib.LIB_PATH), "rn_infer")
+    for mode in ("fused", "ops"):
+        r = subprocess.run([exe, "--arch", "50", "--weights", str(wdir), "--input", str(inp), "--mode", mode],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "max index is 112" in r.stdout
+    bad = subprocess.run([exe, "--arch", "50", "--weights", str(tmp_path / "nope"), "--input", str(inp)],
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "Can't open" in bad.stderr
+    m = R.NativeModel("resnet50", weights_dir=str(wdir))
+    try:
+        assert int(m.forward(finch).argmax(1)[0]) == 112
+    finally:
+        m.close()
+
+
+def test_full_size_batch_properties(model50, finch):
+    """Config 3 size (B=256): the oracle would take minutes here, so check
+    size-independent properties: planted images reproduce their batch-1 logits bit
+    for bit, the batch is deterministic, identical images give identical rows."""
+    B = 256
+    x = R.weights.generate_input(B, seed=3)
+    x[17] = finch[0]
+    x[255] = x[0]
+    full = model50.forward(x, fused=True)
+    assert full.shape == (B, 1000) and np.isfinite(full).all()
+    assert np.array_equal(full[17:18], model50.forward(finch, fused=True))
+    assert np.array_equal(full[255], full[0])
+    assert np.array_equal(full[100:101], model50.forward(x[100:101], fused=True))
+    assert np.array_equal(full, model50.forward(x, fused=True))
+    assert model50.activation_bytes() < 4 * 2**30

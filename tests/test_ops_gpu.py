@@ -1,0 +1,261 @@
+"""Per-op parity on the GPU: every call goes through the C-ABI (librn_hip.so) and is
+checked against the CPU oracle on the same seeded inputs.
+
+Tolerances.  Integer/index results (argmax, shapes) and pure data movement / max /
+relu / add are bit-exact.  Contractions on the matrix-core path sum the same
+products in a different (fixed) k order than the reference's sequential chain, so
+they are compared with rtol 2e-5 / atol 2e-5 * sqrt(K)-scaled magnitude; the direct
+fallback kernel keeps the reference order and is bit-exact with the oracle.
+Batch-norm follows the reference's double-precision expression: <= 1 ulp.
+"""
+import numpy as np
+import pytest
+
+import resnet_c_amd as R
+from oracle import oracle as O
+from resnet_c_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, seed):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+def assert_close(got, want, k_terms):
+    scale = float(np.abs(want).max()) + 1e-6
+    tol = 3e-7 * np.sqrt(k_terms) * scale + 1e-6
+    err = float(np.abs(got - want).max())
+    assert got.shape == want.shape
+    assert err <= tol, f"max err {err:.3e} > tol {tol:.3e} (K={k_terms})"
+
+
+def test_reference_test_cu_patterns(golden_dir):
+    import os
+    k = np.load(os.path.join(golden_dir, "ops_kat.npz"))
+    # small-integer data: every path must be exact
+    assert np.array_equal(ops.conv2d(k["conv_x"], k["conv_w"]), k["conv_y"])
+    assert np.array_equal(ops.linear(k["lin_x"], k["lin_w"], k["lin_b"]), k["lin_y"])
+    assert np.array_equal(ops.relu(k["relu_x"]), k["relu_y"])
+
+
+# B, Cin, Cout, H, W, k, stride, pad  -- direct kernel (Cin % 32 != 0, not stem-shaped)
+DIRECT = [(2, 5, 4, 8, 8, 3, 1, 1), (1, 8, 8, 5, 5, 1, 1, 0), (3, 8, 4, 6, 6, 1, 2, 0),
+          (2, 6, 6, 7, 9, 3, 2, 1), (1, 33, 3, 4, 4, 2, 1, 0), (1, 5, 2, 3, 3, 3, 1, 2)]
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("case", DIRECT)
+def test_conv_direct_is_bit_exact_with_reference_order(case, layout):
+    B, Cin, Cout, H, W, k, s, p = case
+    x, w = rnd((B, Cin, H, W), 1 + sum(case)), rnd((Cout, Cin, k, k), 2 + sum(case))
+    assert np.array_equal(ops.conv2d(x, w, s, p, layout), O.conv2d(x, w, s, p))
+
+
+# matrix-core path: Cin % 32 == 0, and the small-Cin stem form (Cin <= 4, k <= 8)
+GEMM = [
+    (2, 64, 64, 12, 12, 1, 1, 0),    # 1x1, one K tile pair, BN=64
+    (1, 64, 256, 14, 14, 1, 1, 0),   # 1x1 wide output
+    (2, 256, 64, 9, 9, 1, 1, 0),     # ragged M (162 rows): row guards
+    (1, 128, 128, 10, 10, 3, 1, 1),  # 3x3 pad 1
+    (2, 64, 64, 13, 11, 3, 2, 1),    # 3x3 stride 2, odd sizes
+    (1, 256, 512, 8, 8, 1, 2, 0),    # projection shortcut: 1x1 stride 2
+    (2, 32, 96, 7, 7, 3, 1, 1),      # Cout not a multiple of the tile (column guards)
+    (1, 32, 40, 5, 6, 5, 1, 2),      # 5x5
+    (2, 3, 64, 32, 32, 7, 2, 3),     # stem form
+    (1, 3, 64, 224, 224, 7, 2, 3),   # the real stem shape, 98 M tiles
+    (1, 4, 16, 9, 9, 3, 1, 1),       # stem form with Cin = 4
+    (1, 1, 8, 10, 10, 8, 1, 3),      # stem form, k = 8
+    (1, 2, 3, 4, 4, 2, 1, 0),        # tiny
+]
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("case", GEMM)
+def test_conv_gemm_matches_oracle(case, layout):
+    B, Cin, Cout, H, W, k, s, p = case
+    if layout == "nhwc" and Cin < 4:
+        pytest.skip("NHWC small-Cin input takes the direct kernel (covered above)")
+    x, w = rnd((B, Cin, H, W), 11 + sum(case)), rnd((Cout, Cin, k, k), 12 + sum(case))
+    assert_close(ops.conv2d(x, w, s, p, layout), O.conv2d(x, w, s, p), Cin * k * k)
+
+
+def test_conv_zero_padding_is_not_read_as_garbage():
+    # an all-ones image: border outputs count exactly the in-bounds taps
+    x = np.ones((1, 32, 6, 6), dtype=np.float32)
+    w = np.ones((32, 32, 3, 3), dtype=np.float32)
+    got = ops.conv2d(x, w, 1, 1, "nhwc")
+    assert got[0, 0, 0, 0] == 32 * 4 and got[0, 0, 0, 3] == 32 * 6 and got[0, 0, 3, 3] == 32 * 9
+    xs = np.ones((1, 3, 10, 10), dtype=np.float32)
+    ws = np.ones((64, 3, 7, 7), dtype=np.float32)
+    gs = ops.conv2d(xs, ws, 2, 3)
+    assert gs[0, 0, 0, 0] == 3 * 16 and gs[0, 5, 2, 2] == 3 * 49
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 12, 12, 3, 1, 1), (1, 128, 256, 7, 7, 1, 1, 0),
+                                  (2, 3, 64, 20, 20, 7, 2, 3), (1, 6, 5, 6, 6, 3, 1, 1)])
+def test_fused_epilogue_matches_unfused_sequence(case):
+    B, Cin, Cout, H, W, k, s, p = case
+    seed = 100 + sum(case)
+    x, w = rnd((B, Cin, H, W), seed), rnd((Cout, Cin, k, k), seed + 1)
+    g = np.random.default_rng(seed + 2)
+    gamma, beta = g.random(Cout, dtype=np.float32) + 0.5, g.standard_normal(Cout, dtype=np.float32)
+    mean, var = g.standard_normal(Cout, dtype=np.float32), g.random(Cout, dtype=np.float32) + 0.5
+    y = O.conv2d(x, w, s, p)
+    res = rnd(y.shape, seed + 3)
+    want = O.relu_(O.add_(O.batchnorm2d(y, gamma, beta, mean, var), res))
+    sc = (gamma.astype(np.float64) / np.sqrt(var.astype(np.float64) + 1e-5))
+    scale = sc.astype(np.float32)
+    shift = (beta.astype(np.float64) - mean.astype(np.float64) * sc).astype(np.float32)
+    got = ops.conv2d_nhwc_fused(x, w, s, p, scale, shift, res, True)
+    assert_close(got, want, Cin * k * k + 4)
+
+
+def test_batchnorm_fold_entry_point():
+    import ctypes
+    from resnet_c_amd import _lib as L
+    C = 70
+    g = np.random.default_rng(5)
+    w, b = g.random(C, dtype=np.float32) + 0.5, g.standard_normal(C, dtype=np.float32)
+    m, v = g.standard_normal(C, dtype=np.float32), g.random(C, dtype=np.float32) + 0.5
+    ctx = R.get_ctx()
+    T = [R.FloatTensor.from_numpy(a, R.Device.GPU) for a in (w, b, m, v)]
+    sc, sh = R.FloatTensor((C,), R.Device.GPU), R.FloatTensor((C,), R.Device.GPU)
+    L.check(L.lib().rn_batchnorm2d_fold(ctx.handle, *(t.data() for t in T), sc.data(), sh.data(), C),
+            "fold", ctx.handle)
+    s64 = w.astype(np.float64) / np.sqrt(v.astype(np.float64) + 1e-5)
+    assert np.array_equal(sc.numpy(), s64.astype(np.float32))
+    np.testing.assert_allclose(sh.numpy(), (b - m * s64).astype(np.float32), rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("case", [(2, 64, 112, 112, 3, 2, 1), (2, 6, 9, 9, 3, 2, 1), (1, 8, 7, 7, 2, 2, 0),
+                                  (3, 5, 8, 6, 3, 1, 1), (2, 2048, 7, 7, 7, 1, 0), (1, 12, 7, 7, 7, 1, 0)])
+def test_pools_bit_exact(case, layout):
+    B, C, H, W, k, s, p = case
+    x = rnd((B, C, H, W), 7 + sum(case))
+    assert np.array_equal(ops.maxpool2d(x, k, s, p, layout), O.maxpool2d(x, k, s, p))
+    # same tap order and the same two divisions as the reference: bit-exact
+    assert np.array_equal(ops.avgpool2d(x, k, s, p, layout), O.avgpool2d(x, k, s, p))
+
+
+def test_maxpool_all_padding_window_and_nan():
+    x = np.full((1, 4, 3, 3), -5.0, dtype=np.float32)
+    x[0, 0, 1, 1] = np.nan  # fmax suppresses NaN like the reference's device fmax
+    for layout in ("nchw", "nhwc"):
+        got = ops.maxpool2d(x, 3, 2, 1, layout)
+        assert np.array_equal(got, O.maxpool2d(x, 3, 2, 1)) and not np.isnan(got).any()
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("shape", [(2, 64, 56, 56), (3, 7, 5, 5), (1, 256, 14, 14), (2, 5, 4, 6), (4, 8, 1, 1)])
+def test_batchnorm_matches_double_expression(shape, layout):
+    g = np.random.default_rng(sum(shape))
+    x = g.standard_normal(shape, dtype=np.float32) * 3
+    C = shape[1]
+    w, b = g.random(C, dtype=np.float32) + 0.5, g.standard_normal(C, dtype=np.float32)
+    m, v = g.standard_normal(C, dtype=np.float32), g.random(C, dtype=np.float32) + 0.5
+    want = O.batchnorm2d(x, w, b, m, v)
+    got = ops.batchnorm2d(x, w, b, m, v, layout, inplace=True)  # in place, like main.cu:138
+    ulp = np.spacing(np.abs(want).astype(np.float32))
+    assert (np.abs(got - want) <= ulp).all()
+    assert (got != want).mean() < 1e-3  # double-rounding differences are rare
+    assert np.array_equal(ops.batchnorm2d(x, w, b, m, v, layout, inplace=False), got)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 17, 1023, 1024, 1025, 4099, 1 << 20])
+def test_relu_add_any_length_in_place(n):
+    a, b = rnd((n,), n), rnd((n,), n + 1)
+    a[::7] = -a[::7]
+    for inplace in (True, False):
+        assert np.array_equal(ops.relu(a, inplace), np.maximum(a, 0))
+        assert np.array_equal(ops.add(a, b, inplace), a + b)
+    z = np.array([np.nan, -0.0, -1.0, 2.0], dtype=np.float32)
+    assert ops.relu(z).tolist() == [0.0, 0.0, 0.0, 2.0]  # fmax(NaN, 0) == 0 (ops.cu:136)
+
+
+@pytest.mark.parametrize("case", [(3, 16, 8), (256, 2048, 1000), (5, 64, 10), (1, 2048, 1000), (2, 7, 3), (70, 96, 130)])
+def test_linear(case):
+    B, fin, fout = case
+    x, w, b = rnd((B, fin), sum(case)), rnd((fout, fin), 1 + sum(case)), rnd((fout,), 2)
+    want = O.linear(x, w, b)
+    got = ops.linear(x, w, b)
+    if fin % 32:
+        assert np.array_equal(got, want)  # direct kernel: reference order
+    else:
+        assert_close(got, want, fin)
+    assert_close(ops.linear(x, w, None), O.linear(x, w, None), fin)  # bias is nullable
+
+
+def test_argmax_first_maximum_and_nan_rules():
+    g = np.random.default_rng(0)
+    logits = g.standard_normal((9, 1000), dtype=np.float32)
+    logits[1, [10, 500]] = 50.0      # tie -> lower index
+    logits[2, 999] = 60.0            # last lane
+    logits[3, 0] = np.nan            # NaN at 0 is never displaced
+    logits[4, 77] = np.nan           # NaN elsewhere never wins
+    logits[5, :] = -np.inf           # all equal -> 0
+    logits[6, 64] = 70.0             # second pass of lane 0
+    assert np.array_equal(ops.argmax(logits), O.argmax(logits))
+    assert np.array_equal(ops.argmax(logits), R.model.argmax(logits))
+    small = g.standard_normal((3, 5), dtype=np.float32)
+    assert np.array_equal(ops.argmax(small), O.argmax(small))
+
+
+def test_layout_converters_round_trip():
+    import ctypes
+    from resnet_c_amd import _lib as L
+    ctx, lib = R.get_ctx(), L.lib()
+    for shape in [(2, 3, 5, 7), (1, 64, 9, 9), (3, 33, 4, 4), (2, 256, 7, 7), (1, 1, 1, 1)]:
+        B, C, H, W = shape
+        x = rnd(shape, sum(shape))
+        src = R.FloatTensor.from_numpy(x, R.Device.GPU)
+        mid, back = R.FloatTensor(shape, R.Device.GPU), R.FloatTensor(shape, R.Device.GPU)
+        L.check(lib.rn_nchw_to_nhwc(ctx.handle, src.data(), mid.data(), B, C, H, W), "t", ctx.handle)
+        L.check(lib.rn_nhwc_to_nchw(ctx.handle, mid.data(), back.data(), B, C, H, W), "t", ctx.handle)
+        ctx.sync()
+        assert np.array_equal(mid.cpu()._storage.reshape(B, H, W, C), x.transpose(0, 2, 3, 1))
+        assert np.array_equal(back.numpy(), x)
+        for cpad in (4, 8):
+            if cpad < C:
+                continue
+            pad = R.FloatTensor((B, H, W, cpad), R.Device.GPU)
+            L.check(lib.rn_nchw_to_nhwc_pad(ctx.handle, src.data(), pad.data(), B, C, H, W, cpad), "p", ctx.handle)
+            ctx.sync()
+            got = pad.cpu()._storage.reshape(B, H, W, cpad)
+            assert np.array_equal(got[..., :C], x.transpose(0, 2, 3, 1)) and not got[..., C:].any()
+
+
+def test_error_convention_status_not_abort():
+    from resnet_c_amd import _lib as L
+    ctx, lib = R.get_ctx(), L.lib()
+    t = R.FloatTensor((16,), R.Device.GPU)
+    # in-place conv is a precondition failure: status + message, process survives
+    st = lib.rn_conv2d_forward(ctx.handle, t.data(), t.data(), t.data(), 1, 1, 0, 1, 1, 1, 4, 4, 1, 1)
+    assert st == L.RN_ERR_INVALID and b"in place" in lib.rn_last_error(ctx.handle)
+    assert lib.rn_relu_forward(ctx.handle, None, None, 0) == L.RN_OK  # empty tensor is a no-op
+    assert lib.rn_ctx_set_layout(ctx.handle, 7) == L.RN_ERR_INVALID
+    with pytest.raises(R.RnError):
+        R.FloatTensor.loadToCuda("/nonexistent/weights_bin/conv1.weight")
+    # reference behaviour on request: sync + error check after every op
+    ctx.set_sync_each_op(True)
+    try:
+        assert np.array_equal(ops.relu(np.array([-1, 2], dtype=np.float32)), [0, 2])
+    finally:
+        ctx.set_sync_each_op(False)
+
+
+def test_device_tensor_file_round_trip(tmp_path):
+    from resnet_c_amd import _lib as L
+    x = rnd((3, 5), 9)
+    p = tmp_path / "layer1.0.conv1.weight"
+    x.tofile(p)
+    t = R.FloatTensor.loadToCuda(str(p))
+    assert t.shape() == R.Shape((15,)) and t.device == R.Device.GPU
+    assert np.array_equal(t.view((3, 5)).numpy(), x)
+    ctx = R.get_ctx()
+    out = tmp_path / "dump.bin"
+    L.check(L.lib().rn_save_f32_file(ctx.handle, str(out).encode(), t.data(), 15), "save", ctx.handle)
+    assert np.array_equal(np.fromfile(out, dtype=np.float32), x.reshape(-1))
+    with pytest.raises(RuntimeError):
+        t.toDevice(R.Device.GPU)  # same-device copy is unsupported (tensor.cuh:193)
