@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Throughput bench of the hot path: ResNet-50 fp32 forward, batch 256 per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward pass of the whole network over one batch of 256 synthetic
+224x224x3 images that are already resident in HBM (BASELINE.json configs[2]).
+With N GPUs every rank runs the same step on its own 256-image shard of a global
+batch of N*256 (batch split, weights replicated, NO data-path collective -- the
+forward has no cross-image reduction); value = N*256*K / t
+where t is the MAX over ranks of the barrier-bracketed wall time of K steps.
+
+The JSON line also carries
+  roofline      the dominant kernel family (the implicit-GEMM contraction): algorithmic
+                FLOPs of its launches in one forward / their summed HIP-event durations,
+                measured on the library's stream in per-op instrumented forwards run
+                right after the timed region (the timed region itself is uninstrumented);
+  hbm_kernels   the same for the bandwidth-bound kernels (GB/s against 8 TB/s);
+  cpu_baseline  oracle/torch_port.py (a torch.nn.functional port of the reference's
+                pytorch_inference.py, pinned by the golden logits) timed on this host's
+                CPU cores on a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE = {"resnet50": 8.178368512, "resnet101": 15.60, "resnet152": 23.027253248}
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (spec)
+PEAK_HBM_GBS = 8000.0         # HBM3E spec
+
+
+def shard_bounds(total: int, rank: int, world: int):
+    """Contiguous batch split: rank r owns images [lo, hi)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_dist(world: int, backend: str = "nccl"):
+    """Process group for the barrier / max-over-ranks only; returns (rank, local_rank)."""
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank
+
+
+def barrier(world: int):
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+
+
+def max_over_ranks(value: float, world: int, device=None) -> float:
+    if world == 1:
+        return value
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline(arch: str, state, seconds_budget: float = 20.0):
+    """Reference-equivalent PyTorch forward on the host CPU, bounded sample."""
+    import numpy as np
+    import torch
+
+    import resnet_c_amd as R
+    from oracle import torch_port as TP
+
+    t = TP.to_torch(state)
+    threads = torch.get_num_threads()
+    B = 16
+    x = torch.from_numpy(R.weights.generate_input(B, seed=123))
+    TP.resnet_forward(t, x[:2], arch)  # warm-up (thread pool, oneDNN primitives)
+    t0 = time.perf_counter()
+    y = TP.resnet_forward(t, x, arch)
+    one = time.perf_counter() - t0
+    reps = int(max(1, min(8, seconds_budget / max(one, 1e-3) - 1)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        y = TP.resnet_forward(t, x, arch)
+    dt = time.perf_counter() - t0
+    assert np.isfinite(y.numpy()).all()
+    return {"value": round(B * reps / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} forwards of batch {B} ({arch} fp32, torch {torch.__version__} "
+                      f"functional port, {threads} threads of {os.cpu_count()} cpus)"}
+
+
+def summarize_profile(recs, n_forwards: int):
+    """Per-op-family totals per forward from the instrumented forwards."""
+    fam = {}
+    for r in recs:
+        f = fam.setdefault(r["op"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        f["ms"] += r["ms"]
+        f["flops"] += r["flops"]
+        f["bytes"] += r["bytes"]
+        f["launches"] += 1
+    for f in fam.values():
+        for k in ("ms", "flops", "bytes"):
+            f[k] /= n_forwards
+        f["launches"] //= n_forwards
+    return fam
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arch", default="resnet50", choices=sorted(GFLOP_PER_IMAGE))
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--mode", default="fused", choices=["fused", "ops"],
+                    help="fused epilogues (default) or one kernel per reference op")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-forwards", type=int, default=3)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import resnet_c_amd as R
+
+    world = args.gpus
+    rank, local_rank = init_dist(world)
+    if world > 1:
+        assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    R.set_device(local_rank)
+    ctx = R.get_ctx()
+
+    B = args.batch
+    state = R.weights.generate_state(args.arch, seed=0)
+    model = R.NativeModel(args.arch, state=state, ctx=ctx)
+    lo, hi = shard_bounds(world * B, rank, world)
+    # this rank's shard of the global batch: image i depends on (seed, i) only
+    per = 3 * 224 * 224
+    x_host = np.empty((B, 3, 224, 224), dtype=np.float32)
+    for j, i in enumerate(range(lo, hi)):
+        u = R.weights.uniform01("input", per, 0, offset=i * per)
+        x_host[j] = (-2.0 + 4.0 * u).astype(np.float32).reshape(3, 224, 224)
+    x_dev = R.FloatTensor.from_numpy(x_host, R.Device.GPU)
+    logits = R.FloatTensor((B, 1000), R.Device.GPU)
+    fused = args.mode == "fused"
+
+    for _ in range(args.warmup):
+        model.forward_ptr(x_dev.data(), B, logits.data(), fused)
+    ctx.sync()
+
+    barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.forward_ptr(x_dev.data(), B, logits.data(), fused)
+    ctx.sync()
+    torch.cuda.synchronize()
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, world, device=torch.device("cuda", local_rank))
+
+    out = logits.numpy()
+    assert np.isfinite(out).all(), "non-finite logits"
+
+    # per-kernel durations: HIP events on the library's stream around every op
+    model.set_profiling(True)
+    recs = []
+    for _ in range(args.profile_forwards):
+        model.forward_ptr(x_dev.data(), B, logits.data(), fused)
+        recs += model.profile()
+    model.set_profiling(False)
+    fam = summarize_profile(recs, args.profile_forwards)
+
+    if rank != 0:
+        return
+    images = world * B * args.steps
+    value = images / elapsed
+    gemm_names = [k for k in fam if k.startswith("conv2d") or k == "linear"]
+    g_flops = sum(fam[k]["flops"] for k in gemm_names)
+    g_ms = sum(fam[k]["ms"] for k in gemm_names)
+    g_launch = sum(fam[k]["launches"] for k in gemm_names)
+    achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    hbm = {}
+    for k, f in fam.items():
+        if k in gemm_names or f["ms"] <= 0:
+            continue
+        gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
+        hbm[k] = {"launches": f["launches"], "ms_per_forward": round(f["ms"], 4),
+                  "GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    result = {
+        "metric": "images/sec ResNet-50 224x224 fp32 batch=256" if args.arch == "resnet50" and B == 256
+                  else f"images/sec {args.arch} 224x224 fp32 batch={B}",
+        "value": round(value, 2),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (seeded uniform [-2,2) images, generated weights in the reference's "
+                "weights_bin format; inputs resident in HBM)",
+        "config": {"workload": f"{args.arch} fp32 forward, batch {B} per GPU, 224x224 "
+                               "(BASELINE.json configs[2])",
+                   "global_batch": world * B, "batch_per_gpu": B,
+                   "mode": "fused conv+bn+relu(+add) epilogues" if fused else "one kernel per reference op",
+                   "parallelism": f"batch split over {world} GPU(s), weights replicated, no collective"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                     "traffic": None,
+                     "kernel": "conv_gemm_kernel (implicit-GEMM conv2d + fc on v_mfma_f32_32x32x2_f32)",
+                     "launches_per_forward": g_launch,
+                     "flops_per_forward": g_flops, "ms_per_forward": round(g_ms, 4)},
+        "whole_step_mfma_frac": round(value / world * GFLOP_PER_IMAGE[args.arch] / 1e3
+                                      / PEAK_F32_MFMA_TFLOPS, 4),
+        "hbm_kernels": hbm,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.arch, state)
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()
