@@ -72,6 +72,17 @@ struct GemmParams {
 
 constexpr int BK = 32;
 
+__device__ __forceinline__ float finish_nores(float v, float sc, float sh, bool has_scale,
+                                              bool has_shift, int relu)
+{
+    if (has_scale) {
+        v = fmaf(v, sc, sh);
+    } else if (has_shift) {
+        v += sh;
+    }
+    return relu ? fmaxf(v, 0.f) : v;
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 {
@@ -225,31 +236,88 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         __syncthreads();
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // epilogue.  The accumulators go through LDS (free after the K loop) so that global
+    // traffic is row-contiguous float4: C/D map of the 32x32 MFMA is col = lane&31,
+    // row = (e&3) + 8*(e>>2) + 4*(lane>>5); a ds_write_b32 of one register puts 32
+    // consecutive columns of two rows, conflict-free.
+    float *Cs = lds;  // [BM][BN]
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int n = n0 + wc * (BN / 2) + ni * 32 + li;
-        if (n >= p.Cout) continue;
-        const float sc = p.scale ? p.scale[n] : 1.f;
-        const float sh = p.shift ? p.shift[n] : 0.f;
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int mb = m0 + wr * (BM / 2) + mi * 32 + 4 * lh;
+        for (int ni = 0; ni < NI; ++ni) {
+            float *dst = Cs + (wr * (BM / 2) + mi * 32 + 4 * lh) * BN + wc * (BN / 2) + ni * 32 + li;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m < p.M) {
-                    const size_t o = (size_t)m * p.Cout + n;
-                    float v = acc[mi][ni][e];
-                    if (p.scale) {
-                        v = fmaf(v, sc, sh);
-                    } else if (p.shift) {
-                        v += sh;
-                    }
-                    if (p.residual) v += p.residual[o];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.out[o] = v;
-                }
+            for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[mi][ni][e];
+        }
+    __syncthreads();
+
+    constexpr int C4 = BN / 4;        // float4 per tile row
+    constexpr int RPP = 256 / C4;     // tile rows per pass of the block
+    constexpr int PASSES = BM / RPP;
+    const int c4 = t % C4, rr = t / C4;
+    const int n = n0 + c4 * 4;
+    if (n >= p.Cout) return;
+    const bool vec = (p.Cout & 3) == 0;  // then n + 3 < Cout and every row start is 16-B aligned
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (n + j < p.Cout) {
+            if (p.scale) sc[j] = p.scale[n + j];
+            if (p.shift) sh[j] = p.shift[n + j];
+        }
+    }
+    const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
+    auto finish = [&](float v, int j, float res) {
+        if (has_scale) {
+            v = fmaf(v, sc[j], sh[j]);
+        } else if (has_shift) {
+            v += sh[j];
+        }
+        v += res;
+        return p.relu ? fmaxf(v, 0.f) : v;
+    };
+    if (vec) {
+        float4 res[PASSES];
+        if (p.residual) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int m = m0 + rr + ps * RPP;
+                res[ps] = m < p.M ? *reinterpret_cast<const float4 *>(p.residual + (size_t)m * p.Cout + n)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = rr + ps * RPP;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            float4 v = *reinterpret_cast<const float4 *>(Cs + row * BN + c4 * 4);
+            const float4 r = p.residual ? res[ps] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.residual) {
+                v.x = finish(v.x, 0, r.x);
+                v.y = finish(v.y, 1, r.y);
+                v.z = finish(v.z, 2, r.z);
+                v.w = finish(v.w, 3, r.w);
+            } else {
+                // no "+ 0.f": keeps -0.0 results of the plain convolution bit-exact
+                v.x = finish_nores(v.x, sc[0], sh[0], has_scale, has_shift, p.relu);
+                v.y = finish_nores(v.y, sc[1], sh[1], has_scale, has_shift, p.relu);
+                v.z = finish_nores(v.z, sc[2], sh[2], has_scale, has_shift, p.relu);
+                v.w = finish_nores(v.w, sc[3], sh[3], has_scale, has_shift, p.relu);
+            }
+            *reinterpret_cast<float4 *>(p.out + (size_t)m * p.Cout + n) = v;
+        }
+    } else {
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = rr + ps * RPP;
+            const int m = m0 + row;
+            if (m >= p.M) continue;
+            for (int j = 0; j < 4; ++j) {
+                if (n + j >= p.Cout) break;
+                const size_t o = (size_t)m * p.Cout + n + j;
+                const float v = Cs[row * BN + c4 * 4 + j];
+                p.out[o] = p.residual ? finish(v, j, p.residual[o])
+                                      : finish_nores(v, sc[j], sh[j], has_scale, has_shift, p.relu);
             }
         }
     }
@@ -358,12 +426,26 @@ int launch_gemm(rn_ctx *ctx, const float *inp, float *out, const float *packed, 
     p.nk = p.KH * p.KW * p.cseg;
     p.Ktot = p.nk * BK;
 
-    const bool narrow = Cout <= 64;
-    const int BNsel = narrow ? 64 : 128;
+    // tile choice: the contraction is matrix-core bound, so a launch takes about
+    // ceil(tiles / 256 CUs) rounds of one tile's MFMA time; pick the candidate with the
+    // least (rounds * tile area / relative tile efficiency), i.e. the least padded,
+    // best balanced cover of the 256 CUs.
+    static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    static const double cand_eff[4] = {1.00, 0.94, 0.94, 0.86};
+    int BMsel = 128, BNsel = 128;
+    double best = 1e300;
+    for (int ci = 0; ci < 4; ++ci) {
+        const uint64_t tm = rn_ceil_div((uint64_t)p.M, cand[ci][0]);
+        const uint64_t tn = rn_ceil_div(Cout, cand[ci][1]);
+        const double rounds = (double)rn_ceil_div(tm * tn, 256);
+        const double cost = rounds * cand[ci][0] * cand[ci][1] / cand_eff[ci];
+        if (cost < best * 0.999) {
+            best = cost;
+            BMsel = cand[ci][0];
+            BNsel = cand[ci][1];
+        }
+    }
     const uint64_t tiles_n = rn_ceil_div(Cout, BNsel);
-    // prefer 128-row tiles; drop to 64 rows when that would leave CUs idle
-    const bool small = rn_ceil_div((uint64_t)p.M, 128) * tiles_n < 768;
-    const int BMsel = small ? 64 : 128;
     const uint64_t tiles_m = rn_ceil_div((uint64_t)p.M, BMsel);
     p.tiles_n = (int)tiles_n;
     const uint64_t grid = tiles_m * tiles_n;
