@@ -183,7 +183,7 @@ def main():
         model.forward_ptr(x_dev.data(), B, logits.data(), fused)
         recs += model.profile()
     model.set_profiling(False)
-    fam = summarize_profile(recs, args.profile_forwards)
+    fam = summarize_profile(recs, max(1, args.profile_forwards))
 
     if rank != 0:
         return

@@ -49,6 +49,7 @@ bool rn_conv_is_c4(uint64_t Cin, uint64_t k);
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmParams {
     const float *in;
@@ -68,6 +69,9 @@ struct GemmParams {
     int Ktot;      // packed weight row length = KH * KW * cseg * 32
     int nk;        // K tiles
     int tiles_n;
+    int HoWo;
+    unsigned mul_hw, shr_hw, mul_w, shr_w;  // n / d == umulhi(n, mul) >> shr for n < 2^31
+    int in_bytes, w_bytes;
 };
 
 constexpr int BK = 32;
@@ -105,56 +109,70 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     const int c = t & 7;    // 16-byte chunk of the 128-byte row this thread stages
     const int r0 = t >> 3;  // first row; rows r0 + 32*j
 
-    // per staged A row: element offset of tap (0,0) chunk c, and input coordinates
-    int a_off[AP], a_ih[AP], a_iw[AP];
-    {
-        const int HoWo = p.Ho * p.Wo;
+    // Operands are fetched with buffer loads: the descriptor's range check turns an
+    // out-of-range offset into zeros, so a padded tap (or a row past M / Cout) costs
+    // one select on the offset instead of a branch around the load.
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
+    constexpr int kOob = (int)0x80000000;  // >= num_records for every tensor we accept
+
+    // per staged A row: byte offset of tap (0,0) chunk c, and which taps are in bounds:
+    // bit kh of the low half = row ih0+kh inside [0,H), bit kw of the high half = column
+    int a_off[AP], a_mask[AP];
 #pragma unroll
-        for (int j = 0; j < AP; ++j) {
-            const int m = m0 + r0 + 32 * j;
-            if (m < p.M) {
-                const int b = m / HoWo;
-                const int rem = m - b * HoWo;
-                const int oh = rem / p.Wo;
-                const int ow = rem - oh * p.Wo;
-                const int ih0 = oh * p.stride - p.pad;
-                const int iw0 = ow * p.stride - p.pad;
-                a_ih[j] = ih0;
-                a_iw[j] = iw0 + c * p.chunk_dw;
-                a_off[j] = ((b * p.H + ih0) * p.W + iw0) * p.Cs + c * 4;
-            } else {
-                a_ih[j] = -(1 << 28);  // fails every bounds check -> zero rows
-                a_iw[j] = 0;
-                a_off[j] = 0;
-            }
+    for (int j = 0; j < AP; ++j) {
+        const int m = m0 + r0 + 32 * j;
+        if (m < p.M) {
+            const int b = p.HoWo == 1 ? m : (int)(__umulhi((unsigned)m, p.mul_hw) >> p.shr_hw);
+            const int rem = m - b * p.HoWo;
+            const int oh = p.Wo == 1 ? rem : (int)(__umulhi((unsigned)rem, p.mul_w) >> p.shr_w);
+            const int ow = rem - oh * p.Wo;
+            const int ih0 = oh * p.stride - p.pad;
+            const int iw0 = ow * p.stride - p.pad;
+            const int iwc = iw0 + c * p.chunk_dw;
+            a_off[j] = (((b * p.H + ih0) * p.W + iw0) * p.Cs + c * 4) * 4;
+            const int rlo = max(0, -ih0), rhi = min(p.KH, p.H - ih0);
+            const int clo = max(0, -iwc), chi = min(p.KW, p.W - iwc);
+            const int rm = rhi > rlo ? ((1 << rhi) - 1) & ~((1 << rlo) - 1) : 0;
+            const int cm = chi > clo ? ((1 << chi) - 1) & ~((1 << clo) - 1) : 0;
+            a_mask[j] = rm | (cm << 16);
+        } else {
+            a_off[j] = 0;
+            a_mask[j] = 0;
         }
     }
-    // per staged B row
-    const float *b_ptr[BP];
-    bool b_ok[BP];
+    // per staged B row: constant per-thread offset, the K tile goes into the scalar offset
+    int b_off[BP];
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
         const int n = n0 + r0 + 32 * j;
-        b_ok[j] = n < p.Cout;
-        b_ptr[j] = p.w + (size_t)(b_ok[j] ? n : 0) * p.Ktot + c * 4;
+        b_off[j] = n < p.Cout ? (n * p.Ktot + c * 4) * 4 : kOob;
     }
 
     float4 ra[AP], rb[BP];
-    int kh = 0, kw = 0, cs = 0;  // K-loop position of the tile being LOADED
+    int kh = 0, kw = 0, cs = 0;  // K-loop position of the tile being LOADED (wave-uniform)
 
     auto load_tile = [&](int kt) {
-        const int toff = (kh * p.W + kw) * p.Cs + cs * BK;
+        const int s_kh = __builtin_amdgcn_readfirstlane(kh);
+        const int s_kw = __builtin_amdgcn_readfirstlane(kw);
+        const int s_cs = __builtin_amdgcn_readfirstlane(cs);
+        const int toff = ((s_kh * p.W + s_kw) * p.Cs + s_cs * BK) * 4;
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
-            const bool ok = (unsigned)(a_ih[j] + kh) < (unsigned)p.H &&
-                            (unsigned)(a_iw[j] + kw) < (unsigned)p.W;
-            ra[j] = ok ? *reinterpret_cast<const float4 *>(p.in + (a_off[j] + toff))
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
+            const int voff = ok ? a_off[j] + toff : kOob;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0);
+            ra[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                                __uint_as_float(v.w));
         }
+        const int soff = __builtin_amdgcn_readfirstlane(kt) * (BK * 4);
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
-            rb[j] = b_ok[j] ? *reinterpret_cast<const float4 *>(b_ptr[j] + kt * BK)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_off[j], soff, 0);
+            rb[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                                __uint_as_float(v.w));
         }
         // advance to the next tile: segment fastest, then kw, then kh
         if (++cs == p.cseg) {
@@ -395,6 +413,22 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirectParams p)
 
 bool fits_i32(uint64_t v) { return v < (1ull << 31); }
 
+// n / d == umulhi(n, mul) >> shr for 0 <= n < 2^31, d >= 1 (round-up magic number)
+void fast_div(unsigned d, unsigned *mul, unsigned *shr)
+{
+    if (d <= 1) {  // the kernel special-cases a divisor of 1 (fc, 1x1 outputs)
+        *mul = 0;
+        *shr = 0;
+        return;
+    }
+    unsigned lg = 0;
+    while ((1u << lg) < d) ++lg;
+    const unsigned p = 31 + lg;
+    const uint64_t m = ((1ull << p) + d - 1) / d;
+    *mul = (unsigned)m;
+    *shr = p - 32;
+}
+
 // GEMM launch on NHWC data with packed weights.  Caller has checked eligibility.
 int launch_gemm(rn_ctx *ctx, const float *inp, float *out, const float *packed, uint64_t k,
                 uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out, uint64_t B,
@@ -425,6 +459,11 @@ int launch_gemm(rn_ctx *ctx, const float *inp, float *out, const float *packed, 
     p.M = (int)(B * h_out * w_out);
     p.nk = p.KH * p.KW * p.cseg;
     p.Ktot = p.nk * BK;
+    p.HoWo = p.Ho * p.Wo;
+    fast_div((unsigned)p.HoWo, &p.mul_hw, &p.shr_hw);
+    fast_div((unsigned)p.Wo, &p.mul_w, &p.shr_w);
+    p.in_bytes = (int)(B * H * W * (uint64_t)p.Cs * 4);
+    p.w_bytes = (int)(Cout * (uint64_t)p.Ktot * 4);
 
     // tile choice: the contraction is matrix-core bound, so a launch takes about
     // ceil(tiles / 256 CUs) rounds of one tile's MFMA time; pick the candidate with the
@@ -507,11 +546,14 @@ int check_conv_args(rn_ctx *ctx, const float *inp, const float *out, const float
     return RN_OK;
 }
 
-bool gemm_eligible(const void *inp, const void *out, const void *w, uint64_t Cin, uint64_t k)
+bool gemm_eligible(const void *inp, const void *out, const void *w, uint64_t Cin, uint64_t k,
+                   uint64_t in_elems, uint64_t w_elems)
 {
+    // buffer descriptors carry byte counts below 2^31
+    if (in_elems >= (1ull << 29) || w_elems >= (1ull << 29)) return false;
     const bool al = ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out) |
                       reinterpret_cast<uintptr_t>(w)) & 15) == 0;
-    return al && (Cin % 32 == 0 || rn_conv_is_c4(Cin, k));
+    return al && k <= 15 && (Cin % 32 == 0 || rn_conv_is_c4(Cin, k));
 }
 
 }  // namespace
@@ -531,7 +573,9 @@ int rn_conv2d_nhwc_forward(rn_ctx *ctx, const float *inp, float *out, const floa
     if (epilogue && epilogue->residual)
         RN_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(epilogue->residual) & 3) == 0,
                    "misaligned residual");
-    if (gemm_eligible(inp, out, packed_weight, in_channels, kernel_size)) {
+    if (gemm_eligible(inp, out, packed_weight, in_channels, kernel_size,
+                      B * H * W * rn_conv2d_input_channels(in_channels),
+                      rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size))) {
         return launch_gemm(ctx, inp, out, packed_weight, kernel_size, stride, padding, h_out, w_out,
                            B, in_channels, out_channels, H, W, epilogue, "rn_conv2d_nhwc_forward");
     }
@@ -552,7 +596,10 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
                            in_channels, out_channels, H, W));
     RN_REQUIRE(ctx, in_channels >= 1, "in_channels must be >= 1");
     const bool c4 = rn_conv_is_c4(in_channels, kernel_size);
-    const bool fast = in_channels % 32 == 0 || c4;
+    const bool fast = (in_channels % 32 == 0 || c4) && kernel_size <= 15 &&
+                      B * H * W * rn_conv2d_input_channels(in_channels) < (1ull << 29) &&
+                      rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size) <
+                          (1ull << 29);
     if (!fast || (ctx->layout == RN_LAYOUT_NHWC && in_channels < 4)) {
         // exact reference order; OIHW weights as given
         return launch_direct(ctx, inp, out, weight, kernel_size, stride, padding, h_out, w_out, B,
@@ -598,7 +645,8 @@ int rn_linear_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
                "tensor has 2^31 or more elements");
     rn_epilogue ep = {nullptr, bias, nullptr, 0};
     // W is [out][in] row-major == the K-major panel of a 1x1 convolution on a 1x1 image
-    if (in_features % 32 == 0 && gemm_eligible(inp, out, weight, in_features, 1)) {
+    if (in_features % 32 == 0 &&
+        gemm_eligible(inp, out, weight, in_features, 1, B * in_features, out_features * in_features)) {
         return launch_gemm(ctx, inp, out, weight, 1, 1, 0, 1, 1, B, in_features, out_features, 1, 1,
                            &ep, "rn_linear_forward");
     }
