@@ -1,0 +1,45 @@
+"""The C++ veneer (include/rn/*.hpp) with the reference's class names compiles against
+librn_hip.so (CPU) and computes the same numbers as the oracle (GPU)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import resnet_c_amd as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "veneer_smoke")
+    libdir = os.path.dirname(R._lib.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", f"-I{ROOT}/include",
+                    f"{ROOT}/examples/veneer_smoke.cpp", f"-L{libdir}", "-lrn_hip",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                   check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_veneer_compiles_with_a_plain_host_compiler(tmp_path):
+    assert os.path.exists(_build(tmp_path))
+
+
+@pytest.mark.gpu
+def test_veneer_runs_and_matches_oracle(tmp_path):
+    from oracle import oracle as O
+
+    exe = _build(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"out shape \(2, 32, 6, 6\) checksum ([-0-9.e+]+)", r.stdout)
+    assert m, r.stdout
+    B, C, H, W = 2, 32, 6, 6
+    w = (0.01 * (np.arange(C * C * 9) % 7) - 0.02).astype(np.float32).reshape(C, C, 3, 3)
+    x = ((np.arange(B * C * H * W) % 5) - 2.0).astype(np.float32).reshape(B, C, H, W)
+    ones, zeros = np.ones(C, np.float32), np.zeros(C, np.float32)
+    y = O.conv2d(x, w, 1, 1)
+    y = O.relu_(O.batchnorm2d_(y, ones, 0.5 * ones, zeros, ones))
+    y = O.add_(y, x)
+    assert abs(float(m.group(1)) - float(y.astype(np.float64).sum())) < 1e-2
