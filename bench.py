@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--mode", default="fused", choices=["fused", "ops"],
                     help="fused epilogues (default) or one kernel per reference op")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tune", action="store_true", help="skip the per-layer tile tuning pass")
     ap.add_argument("--profile-forwards", type=int, default=3)
     args = ap.parse_args()
 
@@ -158,6 +159,9 @@ def main():
     logits = R.FloatTensor((B, 1000), R.Device.GPU)
     fused = args.mode == "fused"
 
+    if not args.no_tune:
+        # per-layer tile choice for this batch size (speed only; results are bit-identical)
+        model.tune(x_dev.data(), B, logits.data(), fused)
     for _ in range(args.warmup):
         model.forward_ptr(x_dev.data(), B, logits.data(), fused)
     ctx.sync()

@@ -87,6 +87,10 @@ RN_API int rn_ctx_set_layout(rn_ctx *ctx, int layout);
 RN_API int rn_ctx_get_layout(const rn_ctx *ctx);
 /* 1: synchronise and check after every op, like the reference (nn.cu:14-15). Default 0. */
 RN_API int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on);
+/* Tile shape of the contraction kernel: 0 = chosen per launch (default), 1..N = force
+ * candidate i (all candidates give bit-identical results; used by rn_model_tune). */
+RN_API int rn_conv_tile_candidates(void);
+RN_API int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate);
 RN_API void *rn_ctx_stream(rn_ctx *ctx);
 RN_API int rn_ctx_device(const rn_ctx *ctx);
 RN_API int rn_sync(rn_ctx *ctx);
@@ -192,6 +196,10 @@ RN_API const char *rn_model_tensor_key(const rn_model *m, uint64_t index, uint64
 /* input: device NCHW [B,3,224,224]; logits: device [B,1000]. Asynchronous on the stream. */
 RN_API int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *logits,
                             int mode);
+/* Run one forward, then time every tile candidate of every convolution at batch B on the
+ * device (events on the context's stream, on the buffers that forward used) and remember the fastest per layer for
+ * that batch size.  Results do not change (candidates are bit-identical), only speed. */
+RN_API int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode);
 /* per-op timing of the next forwards: 1 = bracket every op with events */
 RN_API int rn_model_set_profiling(rn_model *m, int on);
 /* after a profiled forward + rn_sync: number of ops, then one record per op */

@@ -34,6 +34,8 @@ SIGNATURES = {
     "rn_ctx_set_layout": (c_int, [c_void_p, c_int]),
     "rn_ctx_get_layout": (c_int, [c_void_p]),
     "rn_ctx_set_sync_each_op": (c_int, [c_void_p, c_int]),
+    "rn_conv_tile_candidates": (c_int, []),
+    "rn_ctx_set_conv_tile": (c_int, [c_void_p, c_int]),
     "rn_ctx_stream": (c_void_p, [c_void_p]),
     "rn_ctx_device": (c_int, [c_void_p]),
     "rn_sync": (c_int, [c_void_p]),
@@ -78,6 +80,7 @@ SIGNATURES = {
     "rn_model_finalize": (c_int, [c_void_p]),
     "rn_model_tensor_key": (c_char_p, [c_void_p, u64, POINTER(u64)]),
     "rn_model_forward": (c_int, [c_void_p, fptr, u64, fptr, c_int]),
+    "rn_model_tune": (c_int, [c_void_p, fptr, u64, fptr, c_int]),
     "rn_model_set_profiling": (c_int, [c_void_p, c_int]),
     "rn_model_profile_count": (u64, [c_void_p]),
     "rn_model_profile_get": (c_int, [c_void_p, u64, POINTER(c_char_p), POINTER(c_char_p),

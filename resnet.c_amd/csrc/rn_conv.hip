@@ -472,16 +472,21 @@ int launch_gemm(rn_ctx *ctx, const float *inp, float *out, const float *packed, 
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     static const double cand_eff[4] = {1.00, 0.94, 0.94, 0.86};
     int BMsel = 128, BNsel = 128;
-    double best = 1e300;
-    for (int ci = 0; ci < 4; ++ci) {
-        const uint64_t tm = rn_ceil_div((uint64_t)p.M, cand[ci][0]);
-        const uint64_t tn = rn_ceil_div(Cout, cand[ci][1]);
-        const double rounds = (double)rn_ceil_div(tm * tn, 256);
-        const double cost = rounds * cand[ci][0] * cand[ci][1] / cand_eff[ci];
-        if (cost < best * 0.999) {
-            best = cost;
-            BMsel = cand[ci][0];
-            BNsel = cand[ci][1];
+    if (ctx->conv_tile >= 1 && ctx->conv_tile <= 4) {
+        BMsel = cand[ctx->conv_tile - 1][0];
+        BNsel = cand[ctx->conv_tile - 1][1];
+    } else {
+        double best = 1e300;
+        for (int ci = 0; ci < 4; ++ci) {
+            const uint64_t tm = rn_ceil_div((uint64_t)p.M, cand[ci][0]);
+            const uint64_t tn = rn_ceil_div(Cout, cand[ci][1]);
+            const double rounds = (double)rn_ceil_div(tm * tn, 256);
+            const double cost = rounds * cand[ci][0] * cand[ci][1] / cand_eff[ci];
+            if (cost < best * 0.999) {
+                best = cost;
+                BMsel = cand[ci][0];
+                BNsel = cand[ci][1];
+            }
         }
     }
     const uint64_t tiles_n = rn_ceil_div(Cout, BNsel);

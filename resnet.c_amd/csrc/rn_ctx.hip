@@ -136,6 +136,17 @@ int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on)
     return RN_OK;
 }
 
+int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (candidate < 0 || candidate > rn_conv_tile_candidates())
+        return rn_set_error(ctx, RN_ERR_INVALID, "conv tile candidate %d out of range", candidate);
+    ctx->conv_tile = candidate;
+    return RN_OK;
+}
+
+int rn_conv_tile_candidates(void) { return 4; }
+
 void *rn_ctx_stream(rn_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int rn_ctx_device(const rn_ctx *ctx) { return ctx ? ctx->device : -1; }
 

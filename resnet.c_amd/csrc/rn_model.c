@@ -43,6 +43,7 @@ typedef struct {
     int w, bn_w, bn_b, bn_m, bn_v; /* indices into params */
     float *packed;                 /* K-major panel */
     float *scale, *shift;          /* folded batch-norm */
+    int tile;                      /* tuned contraction tile (0 = per-launch choice) */
 } rn_conv;
 
 typedef struct {
@@ -57,6 +58,15 @@ typedef struct {
     rn_event *start, *stop;
     float ms;
 } rn_prof;
+
+typedef struct {
+    int conv;
+    const float *x;
+    float *y;
+    uint64_t B, H, W;
+    rn_epilogue ep;
+    int has_ep;
+} rn_conv_call;
 
 struct rn_model {
     rn_ctx *ctx;
@@ -74,6 +84,11 @@ struct rn_model {
     uint64_t batch_cap;
     float *x4, *p0, *p1, *dsb, *t1, *t2, *pooled;
     uint64_t act_bytes;
+    /* tile tuning: calls of the last forward, and the batch size the tiles were tuned for */
+    rn_conv_call *calls;
+    int n_calls, recording;
+    uint64_t tuned_B;
+    int tuned_mode, cur_mode;
     /* profiling */
     int profiling;
     rn_prof *prof;
@@ -143,7 +158,8 @@ int rn_model_create(rn_ctx *ctx, rn_model **out, int arch)
     m->params = (rn_param *)calloc((size_t)max_convs * 5 + 2, sizeof(rn_param));
     m->convs = (rn_conv *)calloc((size_t)max_convs, sizeof(rn_conv));
     m->blocks = (rn_block *)calloc((size_t)total_blocks, sizeof(rn_block));
-    if (!m->params || !m->convs || !m->blocks) {
+    m->calls = (rn_conv_call *)calloc((size_t)max_convs, sizeof(rn_conv_call));
+    if (!m->params || !m->convs || !m->blocks || !m->calls) {
         rn_model_destroy(m);
         return RN_ERR_NOMEM;
     }
@@ -229,6 +245,7 @@ int rn_model_destroy(rn_model *m)
     free(m->params);
     free(m->convs);
     free(m->blocks);
+    free(m->calls);
     free(m);
     return RN_OK;
 }
@@ -426,10 +443,26 @@ static int op_conv(rn_model *m, const rn_conv *cv, const float *x, float *y, uin
     double bytes = 4.0 * ((double)(B * H * W * cv->cin) + K * (double)cv->cout +
                           M * (double)cv->cout);
     if (ep && ep->residual) bytes += 4.0 * M * (double)cv->cout;
+    if (m->recording) {
+        rn_conv_call *c = &m->calls[m->n_calls++];
+        c->conv = (int)(cv - m->convs);
+        c->x = x;
+        c->y = y;
+        c->B = B;
+        c->H = H;
+        c->W = W;
+        c->has_ep = ep != NULL;
+        if (ep) c->ep = *ep;
+    }
     TRY(prof_begin(m, ep ? "conv2d+epilogue" : "conv2d", cv->name, 2.0 * M * (double)cv->cout * K,
                    bytes));
-    TRY(rn_conv2d_nhwc_forward(m->ctx, x, y, cv->packed, cv->k, cv->stride, cv->pad, ho, wo, B,
-                               cv->cin, cv->cout, H, W, ep));
+    rn_ctx_set_conv_tile(m->ctx, (m->tuned_B == B && m->tuned_mode == m->cur_mode) ? cv->tile : 0);
+    {
+        const int st = rn_conv2d_nhwc_forward(m->ctx, x, y, cv->packed, cv->k, cv->stride, cv->pad,
+                                              ho, wo, B, cv->cin, cv->cout, H, W, ep);
+        rn_ctx_set_conv_tile(m->ctx, 0);
+        if (st != RN_OK) return st;
+    }
     return prof_end(m);
 }
 
@@ -513,6 +546,7 @@ int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *lo
     if (!m->finalized) return RN_ERR_INVALID;
     TRY(ensure_acts(m, B));
     m->n_prof = 0;
+    m->cur_mode = mode;
     saved_layout = rn_ctx_get_layout(m->ctx);
     rn_ctx_set_layout(m->ctx, RN_LAYOUT_NHWC);
     st = RN_OK;
@@ -564,4 +598,57 @@ int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *lo
     } while (0);
     rn_ctx_set_layout(m->ctx, saved_layout);
     return st;
+}
+
+int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
+{
+    rn_event *e0 = NULL, *e1 = NULL;
+    const int ncand = rn_conv_tile_candidates();
+    int i, c, r, st;
+    if (!m) return RN_ERR_INVALID;
+    /* one recorded forward with the per-launch choice: fills the buffers with real data */
+    m->tuned_B = 0;
+    m->n_calls = 0;
+    m->recording = 1;
+    st = rn_model_forward(m, input_nchw, B, logits, mode);
+    m->recording = 0;
+    if (st != RN_OK) return st;
+    st = rn_event_create(m->ctx, &e0);
+    if (st == RN_OK) st = rn_event_create(m->ctx, &e1);
+    for (i = 0; st == RN_OK && i < m->n_calls; ++i) {
+        const rn_conv_call *k = &m->calls[i];
+        rn_conv *cv = &m->convs[k->conv];
+        const uint64_t ho = rn_conv_output_size(k->H, cv->k, cv->stride, cv->pad);
+        const uint64_t wo = rn_conv_output_size(k->W, cv->k, cv->stride, cv->pad);
+        float best = 1e30f;
+        int best_c = 0;
+        for (c = 0; c <= ncand && st == RN_OK; ++c) { /* 0 = the per-launch choice itself */
+            float ms = 1e30f;
+            rn_ctx_set_conv_tile(m->ctx, c);
+            for (r = 0; r < 4 && st == RN_OK; ++r) {
+                float t = 0.f;
+                st = rn_event_record(m->ctx, e0);
+                if (st == RN_OK)
+                    st = rn_conv2d_nhwc_forward(m->ctx, k->x, k->y, cv->packed, cv->k, cv->stride,
+                                                cv->pad, ho, wo, k->B, cv->cin, cv->cout, k->H, k->W,
+                                                k->has_ep ? &k->ep : NULL);
+                if (st == RN_OK) st = rn_event_record(m->ctx, e1);
+                if (st == RN_OK) st = rn_event_elapsed_ms(e0, e1, &t);
+                if (r > 0 && t < ms) ms = t; /* first repetition warms the caches */
+            }
+            if (ms < best * 0.995f) { /* ties keep the earlier (default) candidate */
+                best = ms;
+                best_c = c;
+            }
+        }
+        cv->tile = best_c;
+    }
+    rn_ctx_set_conv_tile(m->ctx, 0);
+    rn_event_destroy(e0);
+    rn_event_destroy(e1);
+    if (st != RN_OK) return st;
+    m->tuned_B = B;
+    m->tuned_mode = mode;
+    /* leave the buffers and the logits as a normal forward would */
+    return rn_model_forward(m, input_nchw, B, logits, mode);
 }

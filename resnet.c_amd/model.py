@@ -251,6 +251,12 @@ class NativeModel:
         self.ctx.sync()
         return out.numpy()
 
+    def tune(self, input_ptr: int, B: int, logits_ptr: int, fused: bool = True) -> None:
+        """Pick the fastest contraction tile per layer for batch B (results unchanged)."""
+        L.check(L.lib().rn_model_tune(self.handle, input_ptr, B, logits_ptr,
+                                      L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS),
+                "rn_model_tune", self.ctx.handle)
+
     def set_profiling(self, on: bool) -> None:
         L.check(L.lib().rn_model_set_profiling(self.handle, int(on)), "rn_model_set_profiling")
 

@@ -79,6 +79,31 @@ def test_fused_and_reference_op_sequence_agree(model50):
     assert np.array_equal(a.argmax(1), b.argmax(1))
 
 
+def test_tile_tuning_changes_speed_not_results(model50):
+    """Every tile candidate of the contraction sums each output in the same order, so the
+    tuned model is bit-identical to the untuned one (and so is every forced candidate)."""
+    from resnet_c_amd import _lib as L
+    x = R.weights.generate_input(4, seed=31)
+    base = model50.forward(x, fused=True)
+    xin = R.FloatTensor.from_numpy(x, R.Device.GPU)
+    out = R.FloatTensor((4, 1000), R.Device.GPU)
+    model50.tune(xin.data(), 4, out.data(), fused=True)
+    model50.ctx.sync()
+    assert np.array_equal(out.numpy(), base)
+    assert np.array_equal(model50.forward(x, fused=True), base)
+    w = np.random.default_rng(1).standard_normal((96, 64, 3, 3), dtype=np.float32)
+    xs = np.random.default_rng(2).standard_normal((3, 64, 9, 9), dtype=np.float32)
+    ref = R.ops.conv2d(xs, w, 1, 1, "nhwc")
+    ctx = R.get_ctx()
+    for cand in range(1, L.lib().rn_conv_tile_candidates() + 1):
+        L.check(L.lib().rn_ctx_set_conv_tile(ctx.handle, cand), "tile", ctx.handle)
+        try:
+            assert np.array_equal(R.ops.conv2d(xs, w, 1, 1, "nhwc"), ref), cand
+        finally:
+            L.lib().rn_ctx_set_conv_tile(ctx.handle, 0)
+    assert L.lib().rn_ctx_set_conv_tile(ctx.handle, 99) == L.RN_ERR_INVALID
+
+
 def test_profile_accounts_for_every_reference_op(model50, finch):
     model50.set_profiling(True)
     try:

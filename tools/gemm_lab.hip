@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
+#include <cmath>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -179,22 +181,382 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(const float *A, const fl
     }
 }
 
-template <int BM, int BN, int LAB, int WPS>
-float run(const float *A, const float *B, float *C, int M, int N, int K, int reps)
+
+// ---------------------------------------------------------------------------------
+// Wave-specialised variant: 8 waves per block.  Waves 0-3 (one per SIMD) only read
+// fragments from LDS and issue MFMAs; waves 4-7 only fetch operands (buffer loads,
+// D tiles deep in registers) and write them into a 3-stage LDS ring.  One barrier per
+// K tile; B_t = "tile t published".  Consumers execute B_{i+1} at the start of
+// iteration i, so a producer passing B_t knows tile t-2 has been consumed and stage
+// (t+1)%3 is free.
+template <int BM, int BN, int D, int SAME = 0>
+__global__ __launch_bounds__(512, 2) void gemm_ws_kernel(const float *A, const float *B, float *C,
+                                                         int M, int N, int K, int tiles_n)
+{
+    constexpr int AP = BM / 32, BP = BN / 32, MI = BM / 64, NI = BN / 64;
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int S = 3;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_n = (int)(logical % (unsigned)tiles_n), tile_m = (int)(logical / (unsigned)tiles_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = K / BK;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    f32x16 acc[MI][NI];
+    const int lane = threadIdx.x & 63, cw = wave & 3, wr = cw >> 1, wc = cw & 1, li = lane & 31, lh = lane >> 5;
+
+    if (wave >= 4) {
+        // ---------------- producer ----------------
+        const int t = threadIdx.x - 256, c = t & 7, r0 = t >> 3;
+        const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, M * K * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, N * K * 4, 0x00020000);
+        int a_off[AP], b_off[BP];
+#pragma unroll
+        for (int j = 0; j < AP; ++j) a_off[j] = ((m0 + r0 + 32 * j) * K + c * 4) * 4;
+#pragma unroll
+        for (int j = 0; j < BP; ++j) b_off[j] = ((n0 + r0 + 32 * j) * K + c * 4) * 4;
+        u32x4 ra[D][AP], rb[D][BP];
+        auto issue = [&](int kt, u32x4 (&xa)[AP], u32x4 (&xb)[BP]) {
+            const int soff = SAME ? 0 : kt * BK * 4;
+#pragma unroll
+            for (int j = 0; j < AP; ++j) xa[j] = __builtin_amdgcn_raw_buffer_load_b128(ra_, a_off[j], soff, 0);
+#pragma unroll
+            for (int j = 0; j < BP; ++j) xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rb_, b_off[j], soff, 0);
+        };
+        auto stage_write = [&](int st, u32x4 (&xa)[AP], u32x4 (&xb)[BP]) {
+            float *As = lds + st * STAGE, *Bs = As + BM * BK;
+#pragma unroll
+            for (int j = 0; j < AP; ++j) {
+                const int row = r0 + 32 * j, pc = c ^ ((row >> 1) & 7);
+                *reinterpret_cast<u32x4 *>(As + row * BK + pc * 4) = xa[j];
+            }
+#pragma unroll
+            for (int j = 0; j < BP; ++j) {
+                const int row = r0 + 32 * j, pc = c ^ ((row >> 1) & 7);
+                *reinterpret_cast<u32x4 *>(Bs + row * BK + pc * 4) = xb[j];
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < nk) issue(d, ra[d], rb[d]);
+        int st = 0;
+        for (int t0 = 0; t0 < nk; t0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int kt = t0 + d;
+                if (kt < nk) {
+                    stage_write(st, ra[d], rb[d]);
+                    if (kt + D < nk) issue(kt + D, ra[d], rb[d]);
+                    st = st == S - 1 ? 0 : st + 1;
+                    __syncthreads();  // B_kt
+                }
+            }
+        }
+        __syncthreads();  // E0
+        __syncthreads();  // E1
+    } else {
+        // ---------------- consumer ----------------
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+        const int sw = (li >> 1) & 7;
+        const int a_base = (wr * (BM / 2) + li) * BK, b_base = BM * BK + (wc * (BN / 2) + li) * BK;
+        float4 fa[2][MI], fb[2][NI];
+        auto read_frags = [&](int st, int ks, float4 (&xa)[MI], float4 (&xb)[NI]) {
+            const float *base = lds + st * STAGE;
+            const int pc = ((2 * ks + lh) ^ sw) * 4;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const float4 *>(base + a_base + mi * 32 * BK + pc);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) xb[ni] = *reinterpret_cast<const float4 *>(base + b_base + ni * 32 * BK + pc);
+        };
+        auto mfmas = [&](float4 (&xa)[MI], float4 (&xb)[NI]) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].x, xb[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].y, xb[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].z, xb[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].w, xb[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        };
+        __builtin_amdgcn_s_setprio(3);
+        __syncthreads();  // B_0
+        read_frags(0, 0, fa[0], fb[0]);
+        int st = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int nst = st == S - 1 ? 0 : st + 1;
+            if (i + 1 < nk) __syncthreads();  // B_{i+1}
+            read_frags(st, 1, fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(st, 2, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(st, 3, fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < nk) read_frags(nst, 0, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            st = nst;
+        }
+        __syncthreads();  // E0: every wave is done with the ring
+        float *Cs = lds;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                float *dst = Cs + (wr * (BM / 2) + mi * 32 + 4 * lh) * BN + wc * (BN / 2) + ni * 32 + li;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[mi][ni][e];
+            }
+        __syncthreads();  // E1
+    }
+    // all 8 waves: row-contiguous float4 stores
+    constexpr int C4 = BN / 4, RPP = 512 / C4, PASSES = BM / RPP;
+    const int t = threadIdx.x, c4 = t % C4, rr = t / C4;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int row = rr + ps * RPP;
+        const float4 v = *reinterpret_cast<const float4 *>(lds + row * BN + c4 * 4);
+        *reinterpret_cast<float4 *>(C + (size_t)(m0 + row) * N + n0 + c4 * 4) = v;
+    }
+}
+
+template <int BM, int BN, int D, int SAME = 0>
+float run_ws(const float *A, const float *B, float *C, int M, int N, int K, int reps)
 {
     const int tn = N / BN, tm = M / BM;
+    const size_t lds_bytes = 3 * (BM + BN) * BK * 4;
+    hipFuncSetAttribute((const void *)gemm_ws_kernel<BM, BN, D, SAME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) gemm_kernel<BM, BN, LAB, WPS><<<tm * tn, 256>>>(A, B, C, M, N, K, tn);
+    for (int i = 0; i < 2; ++i) gemm_ws_kernel<BM, BN, D, SAME><<<tm * tn, 512, lds_bytes>>>(A, B, C, M, N, K, tn);
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) gemm_kernel<BM, BN, LAB, WPS><<<tm * tn, 256>>>(A, B, C, M, N, K, tn);
+    for (int i = 0; i < reps; ++i) gemm_ws_kernel<BM, BN, D, SAME><<<tm * tn, 512, lds_bytes>>>(A, B, C, M, N, K, tn);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
-    printf("  BM=%d BN=%d WPS=%d LAB=%2d%s%s%s%s%s%s : %.3f ms  %.1f TF\n", BM, BN, WPS, LAB, (LAB & DEEP) ? " deep" : (LAB & SAME_TILE) ? " sametile" : "",
+    printf("  WS%s BM=%d BN=%d D=%d : %.3f ms  %.1f TF  (%s)\n", SAME ? " sametile" : "", BM, BN, D, ms, 2.0 * M * N * K / ms / 1e9,
+           hipGetErrorString(hipGetLastError()));
+    return ms;
+}
+
+
+// ---------------------------------------------------------------------------------
+// LDS-DMA variant: operands go global -> LDS with global_load_lds (16 B per lane,
+// 1 KiB = 8 rows x 128 B per wave instruction, swizzle applied on the SOURCE address),
+// no VGPR staging and no ds_write.  S-stage ring, tiles t+1 .. t+S-1 in flight while
+// tile t is multiplied; one raw s_barrier per K tile with a counted vmcnt.
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+template <int BM, int BN, int S, int PIN, int SAME = 0>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const float *A, const float *B, float *C,
+                                                       int M, int N, int K, int tiles_n)
+{
+    constexpr int MI = BM / 64, NI = BN / 64;
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int PA = BM / 32, PB = BN / 32;  // 1-KiB pieces per wave per tile (A, B)
+    constexpr int NPIECE = PA + PB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_n = (int)(logical % (unsigned)tiles_n), tile_m = (int)(logical / (unsigned)tiles_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = K / BK;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+    // DMA piece geometry: piece p covers rows 8p..8p+7; this lane fills (row 8p + lane/8,
+    // physical chunk lane%8) and therefore fetches logical chunk pc ^ ((row>>1)&7).
+    const int prow = lane >> 3, pc = lane & 7;
+    const float *a_src[PA];
+    const float *b_src[PB];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int row = 8 * (wave + 4 * j) + prow;
+        a_src[j] = A + (size_t)(m0 + row) * K + ((pc ^ ((row >> 1) & 7)) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int row = 8 * (wave + 4 * j) + prow;
+        b_src[j] = B + (size_t)(n0 + row) * K + ((pc ^ ((row >> 1) & 7)) * 4);
+    }
+    // The DMA is issued from inline asm so that hipcc's waitcnt pass does not see a
+    // pending LDS write (it would put vmcnt(0) in front of every ds_read); completion is
+    // counted by hand below.  M0 carries the wave-uniform LDS byte address.
+    const unsigned lds_base = (unsigned)(uintptr_t)((lds_void *)lds);
+    auto glds16 = [&](const float *gsrc, unsigned lds_dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_dst)
+                     : "memory");
+    };
+    auto dma_tile = [&](int kt, int st) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(st * STAGE + wave * 256) * 4u);
+        const unsigned sb = sa + BM * BK * 4;
+        if (SAME) kt = 0;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) glds16(a_src[j] + kt * BK, sa + j * 4096);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) glds16(b_src[j] + kt * BK, sb + j * 4096);
+    };
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    const int sw = (li >> 1) & 7;
+    const int a_base = (wr * (BM / 2) + li) * BK, b_base = BM * BK + (wc * (BN / 2) + li) * BK;
+    float4 fa[2][MI], fb[2][NI];
+    auto read_frags = [&](int st, int ks, float4 (&xa)[MI], float4 (&xb)[NI]) {
+        const float *base = lds + st * STAGE;
+        const int pcs = ((2 * ks + lh) ^ sw) * 4;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) xa[mi] = *reinterpret_cast<const float4 *>(base + a_base + mi * 32 * BK + pcs);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) xb[ni] = *reinterpret_cast<const float4 *>(base + b_base + ni * 32 * BK + pcs);
+    };
+    auto mfmas = [&](float4 (&xa)[MI], float4 (&xb)[NI]) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].x, xb[ni].x, acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].y, xb[ni].y, acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].z, xb[ni].z, acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].w, xb[ni].w, acc[mi][ni], 0, 0, 0);
+            }
+    };
+    // prologue: S-1 tiles in flight
+#pragma unroll
+    for (int d = 0; d < S - 1; ++d)
+        if (d < nk) dma_tile(d, d);
+    int st = 0;
+    for (int i = 0; i < nk; ++i) {
+        // retire this wave's pieces of tile i (younger tiles may stay in flight)
+        const int younger = min(S - 2, nk - 1 - i);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIECE) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        // stage (i-1)%S is free now (everyone finished tile i-1): refill it with tile i+S-1
+        if (i + S - 1 < nk) dma_tile(i + S - 1, st == 0 ? S - 1 : st - 1);
+        if (PIN) {
+            read_frags(st, 0, fa[0], fb[0]);
+            read_frags(st, 1, fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(st, 2, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(st, 3, fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                read_frags(st, ks, fa[0], fb[0]);
+                mfmas(fa[0], fb[0]);
+            }
+        }
+        st = st == S - 1 ? 0 : st + 1;
+    }
+    asm volatile("s_barrier" ::: "memory");
+    float *Cs = lds;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            float *dst = Cs + (wr * (BM / 2) + mi * 32 + 4 * lh) * BN + wc * (BN / 2) + ni * 32 + li;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[mi][ni][e];
+        }
+    __syncthreads();
+    constexpr int C4 = BN / 4, RPP = 256 / C4, PASSES = BM / RPP;
+    const int c4 = t % C4, rr = t / C4;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int row = rr + ps * RPP;
+        const float4 v = *reinterpret_cast<const float4 *>(lds + row * BN + c4 * 4);
+        *reinterpret_cast<float4 *>(C + (size_t)(m0 + row) * N + n0 + c4 * 4) = v;
+    }
+}
+
+template <int BM, int BN, int S, int PIN, int SAME = 0>
+float run_dma(const float *A, const float *B, float *C, int M, int N, int K, int reps)
+{
+    const int tn = N / BN, tm = M / BM;
+    size_t lds_bytes = (size_t)S * (BM + BN) * BK * 4;
+    if (lds_bytes < (size_t)BM * BN * 4) lds_bytes = (size_t)BM * BN * 4;
+    hipFuncSetAttribute((const void *)gemm_dma_kernel<BM, BN, S, PIN, SAME>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) gemm_dma_kernel<BM, BN, S, PIN, SAME><<<tm * tn, 256, lds_bytes>>>(A, B, C, M, N, K, tn);
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) gemm_dma_kernel<BM, BN, S, PIN, SAME><<<tm * tn, 256, lds_bytes>>>(A, B, C, M, N, K, tn);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("  DMA%s BM=%d BN=%d S=%d pin=%d lds=%zuK : %.3f ms  %.1f TF  (%s)\n", SAME ? " sametile" : "", BM, BN, S, PIN, lds_bytes / 1024, ms,
+           2.0 * M * N * K / ms / 1e9, hipGetErrorString(hipGetLastError()));
+    return ms;
+}
+
+static double check(const float *C, const float *Cref, size_t n)
+{
+    std::vector<float> a(n), b(n);
+    hipMemcpy(a.data(), C, n * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(b.data(), Cref, n * 4, hipMemcpyDeviceToHost);
+    double mx = 0;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, (double)fabsf(a[i] - b[i]));
+    return mx;
+}
+
+template <int BM, int BN, int LAB, int WPS>
+float run(const float *A, const float *B, float *C, int M, int N, int K, int reps, int dyn = 0)
+{
+    const int tn = N / BN, tm = M / BM;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    if (dyn) hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, LAB, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    for (int i = 0; i < 2; ++i) gemm_kernel<BM, BN, LAB, WPS><<<tm * tn, 256, dyn>>>(A, B, C, M, N, K, tn);
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) gemm_kernel<BM, BN, LAB, WPS><<<tm * tn, 256, dyn>>>(A, B, C, M, N, K, tn);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("  %sBM=%d BN=%d WPS=%d LAB=%2d%s%s%s%s%s%s : %.3f ms  %.1f TF\n", dyn ? "[1 block/CU] " : "", BM, BN, WPS, LAB, (LAB & DEEP) ? " deep" : (LAB & SAME_TILE) ? " sametile" : "",
            (LAB & NO_GLOBAL) ? " -global" : "", (LAB & NO_STAGE) ? " -stage" : "",
            (LAB & NO_LDSREAD) ? " -ldsread" : "", (LAB & PRIO) ? " +prio" : "",
            (LAB & NO_BARRIER) ? " -barrier" : "", ms, 2.0 * M * N * K / ms / 1e9);
@@ -214,7 +576,42 @@ int main()
     hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
     printf("M=%d N=%d K=%d  (%.1f GFLOP)\n", M, N, K, 2.0 * M * N * K / 1e9);
     const int R = 10;
+    float *C2;
+    hipMalloc(&C2, (size_t)M * N * 4);
     run<128, 128, 0, 2>(A, B, C, M, N, K, R);
+    run_dma<128, 128, 3, 0>(A, B, C2, M, N, K, R);
+    printf("    max|dma - base| = %g\n", check(C2, C, (size_t)M * N));
+    run_dma<128, 128, 3, 1>(A, B, C2, M, N, K, R);
+    printf("    max|dma - base| = %g\n", check(C2, C, (size_t)M * N));
+    run_dma<128, 128, 3, 0, 1>(A, B, C2, M, N, K, R);
+    run_dma<128, 128, 3, 1, 1>(A, B, C2, M, N, K, R);
+    run_dma<128, 64, 3, 0, 1>(A, B, C2, M, N, K, R);
+    run_dma<128, 64, 3, 1, 1>(A, B, C2, M, N, K, R);
+    run_dma<64, 64, 4, 1, 1>(A, B, C2, M, N, K, R);
+    run_dma<128, 64, 3, 0>(A, B, C2, M, N, K, R);
+    run_dma<128, 64, 3, 1>(A, B, C2, M, N, K, R);
+    printf("    max|dma - base| = %g\n", check(C2, C, (size_t)M * N));
+    run_dma<128, 64, 4, 1>(A, B, C2, M, N, K, R);
+    run_dma<64, 64, 3, 1>(A, B, C2, M, N, K, R);
+    run_dma<64, 64, 4, 1>(A, B, C2, M, N, K, R);
+    return 0;
+    run<128, 128, NO_GLOBAL | NO_STAGE | NO_LDSREAD | NO_BARRIER, 2>(A, B, C, M, N, K, R, 90 * 1024);
+    run<128, 128, NO_GLOBAL | NO_STAGE | NO_BARRIER, 2>(A, B, C, M, N, K, R, 90 * 1024);
+    run<128, 128, NO_GLOBAL | NO_STAGE, 2>(A, B, C, M, N, K, R, 90 * 1024);
+    run<128, 128, NO_GLOBAL, 2>(A, B, C, M, N, K, R, 90 * 1024);
+    run<128, 128, 0, 2>(A, B, C, M, N, K, R, 90 * 1024);
+    run_ws<128, 128, 2>(A, B, C2, M, N, K, R);
+    printf("    max|ws - base| = %g\n", check(C2, C, (size_t)M * N));
+    run_ws<128, 128, 1>(A, B, C2, M, N, K, R);
+    run_ws<128, 128, 1, 1>(A, B, C2, M, N, K, R);
+    run_ws<128, 64, 1>(A, B, C2, M, N, K, R);
+    run_ws<128, 64, 1, 1>(A, B, C2, M, N, K, R);
+    run_ws<64, 64, 1>(A, B, C2, M, N, K, R);
+    run_ws<128, 64, 2>(A, B, C2, M, N, K, R);
+    printf("    max|ws - base| = %g\n", check(C2, C, (size_t)M * N));
+    run_ws<128, 64, 3>(A, B, C2, M, N, K, R);
+    run_ws<64, 64, 3>(A, B, C2, M, N, K, R);
+    return 0;
     run<128, 128, NO_GLOBAL, 2>(A, B, C, M, N, K, R);
     run<128, 128, NO_GLOBAL | NO_STAGE, 2>(A, B, C, M, N, K, R);
     run<128, 128, NO_GLOBAL | NO_STAGE | NO_BARRIER, 2>(A, B, C, M, N, K, R);

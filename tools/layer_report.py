@@ -19,12 +19,15 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--mode", default="fused")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--tune", action="store_true")
     a = ap.parse_args()
     state = R.weights.generate_state(a.arch, 0)
     m = R.NativeModel(a.arch, state=state)
     x = R.FloatTensor.from_numpy(R.weights.generate_input(a.batch, 0), R.Device.GPU)
     out = R.FloatTensor((a.batch, 1000), R.Device.GPU)
     fused = a.mode == "fused"
+    if a.tune:
+        m.tune(x.data(), a.batch, out.data(), fused)
     for _ in range(2):
         m.forward_ptr(x.data(), a.batch, out.data(), fused)
     m.set_profiling(True)
