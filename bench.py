@@ -45,7 +45,9 @@ def shard_bounds(total: int, rank: int, world: int):
 
 
 def init_dist(world: int, backend: str = "nccl"):
-    """Process group for the barrier / max-over-ranks only; returns (rank, local_rank)."""
+    """Process group for the barrier / max-over-ranks only; returns (rank, local_rank).
+    The data path has no collective.  RCCL ("nccl") is used when it initialises; a node
+    where it cannot (e.g. ranks sharing one device in a rehearsal) falls back to gloo."""
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
@@ -57,11 +59,28 @@ def init_dist(world: int, backend: str = "nccl"):
     return rank, local_rank
 
 
+_reduce_device = None
+
+
+def _coord_tensor(value: float):
+    """A 1-element tensor on whatever device the process group reduces on."""
+    import torch
+    import torch.distributed as dist
+
+    dev = _reduce_device if dist.get_backend() == "nccl" else None
+    return torch.tensor([value], dtype=torch.float64, device=dev)
+
+
 def barrier(world: int):
     if world > 1:
         import torch.distributed as dist
 
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            import torch
+
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float, world: int, device=None) -> float:
@@ -70,7 +89,9 @@ def max_over_ranks(value: float, world: int, device=None) -> float:
     import torch
     import torch.distributed as dist
 
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    global _reduce_device
+    _reduce_device = device
+    t = _coord_tensor(value)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -138,11 +159,14 @@ def main():
     import resnet_c_amd as R
 
     world = args.gpus
-    rank, local_rank = init_dist(world)
+    ndev = torch.cuda.device_count()
     if world > 1:
         assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run"
-    torch.cuda.set_device(local_rank)
-    R.set_device(local_rank)
+    shared = world > ndev  # rehearsal on a box with fewer GPUs than ranks: ranks share devices
+    rank, local_rank = init_dist(world, backend="gloo" if shared else "nccl")
+    device_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(device_index)
+    R.set_device(device_index)
     ctx = R.get_ctx()
 
     B = args.batch
@@ -175,7 +199,7 @@ def main():
     torch.cuda.synchronize()
     barrier(world)
     elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, world, device=torch.device("cuda", local_rank))
+    elapsed = max_over_ranks(elapsed, world, device=torch.device("cuda", device_index))
 
     out = logits.numpy()
     assert np.isfinite(out).all(), "non-finite logits"
