@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 GFLOP_PER_IMAGE = {"resnet50": 8.178368512, "resnet101": 15.60, "resnet152": 23.027253248}
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (spec)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak (spec, no sparsity)
 
 
 def shard_bounds(total: int, rank: int, world: int):
@@ -148,6 +149,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--mode", default="fused", choices=["fused", "ops"],
                     help="fused epilogues (default) or one kernel per reference op")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage type of activations/weights (accumulation is always fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true", help="skip the per-layer tile tuning pass")
     ap.add_argument("--profile-forwards", type=int, default=3)
@@ -171,7 +174,7 @@ def main():
 
     B = args.batch
     state = R.weights.generate_state(args.arch, seed=0)
-    model = R.NativeModel(args.arch, state=state, ctx=ctx)
+    model = R.NativeModel(args.arch, state=state, ctx=ctx, dtype=args.dtype)
     lo, hi = shard_bounds(world * B, rank, world)
     # this rank's shard of the global batch: image i depends on (seed, i) only
     per = 3 * 224 * 224
@@ -220,6 +223,7 @@ def main():
     gemm_names = [k for k in fam if k.startswith("conv2d") or k == "linear"]
     g_flops = sum(fam[k]["flops"] for k in gemm_names)
     g_ms = sum(fam[k]["ms"] for k in gemm_names)
+    g_bytes = sum(fam[k]["bytes"] for k in gemm_names)
     g_launch = sum(fam[k]["launches"] for k in gemm_names)
     achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
     hbm = {}
@@ -229,9 +233,12 @@ def main():
         gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
         hbm[k] = {"launches": f["launches"], "ms_per_forward": round(f["ms"], 4),
                   "GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    prec = "fp32" if args.dtype == "f32" else "bf16"
     result = {
-        "metric": "images/sec ResNet-50 224x224 fp32 batch=256" if args.arch == "resnet50" and B == 256
-                  else f"images/sec {args.arch} 224x224 fp32 batch={B}",
+        "metric": "images/sec ResNet-50 224x224 fp32 batch=256"
+                  if args.arch == "resnet50" and B == 256 and args.dtype == "f32"
+                  else f"images/sec {args.arch} 224x224 {prec} batch={B}",
         "value": round(value, 2),
         "unit": "images/s",
         "n_gpus": world,
@@ -241,22 +248,25 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic (seeded uniform [-2,2) images, generated weights in the reference's "
                 "weights_bin format; inputs resident in HBM)",
-        "config": {"workload": f"{args.arch} fp32 forward, batch {B} per GPU, 224x224 "
-                               "(BASELINE.json configs[2])",
+        "config": {"workload": f"{args.arch} {prec} forward, batch {B} per GPU, 224x224 "
+                               + ("(BASELINE.json configs[2])" if args.dtype == "f32" and args.arch == "resnet50"
+                                  else "(BASELINE.json configs[3], per-GPU shard)" if args.dtype == "bf16"
+                                  else "(BASELINE.json configs[4])"),
                    "global_batch": world * B, "batch_per_gpu": B,
                    "mode": "fused conv+bn+relu(+add) epilogues" if fused else "one kernel per reference op",
                    "parallelism": f"batch split over {world} GPU(s), weights replicated, no collective"},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
+                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": None,
-                     "kernel": "conv_gemm_kernel (implicit-GEMM conv2d + fc on v_mfma_f32_32x32x2_f32)",
+                     "kernel": "conv_gemm_kernel (implicit-GEMM conv2d + fc on " +
+                               ("v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else "v_mfma_f32_32x32x16_bf16)"),
+                     "hbm_GBps": round(g_bytes / (g_ms * 1e-3) / 1e9, 1) if g_ms > 0 else 0.0,
                      "launches_per_forward": g_launch,
                      "flops_per_forward": g_flops, "ms_per_forward": round(g_ms, 4)},
-        "whole_step_mfma_frac": round(value / world * GFLOP_PER_IMAGE[args.arch] / 1e3
-                                      / PEAK_F32_MFMA_TFLOPS, 4),
+        "whole_step_mfma_frac": round(value / world * GFLOP_PER_IMAGE[args.arch] / 1e3 / peak, 4),
         "hbm_kernels": hbm,
     }
     if world == 1 and not args.no_cpu_baseline:

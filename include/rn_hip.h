@@ -74,6 +74,9 @@ enum {
 
 enum { RN_LAYOUT_NCHW = 0, RN_LAYOUT_NHWC = 1 };
 
+/* element types of the engine-side ("_dt") entry points; accumulation is always fp32 */
+enum { RN_DTYPE_F32 = 0, RN_DTYPE_BF16 = 1 };
+
 /* forward modes of rn_model_forward */
 enum {
     RN_FWD_REFERENCE_OPS = 0, /* one kernel per reference op, same sequence as main.cu:168-226 */
@@ -167,7 +170,8 @@ RN_API int rn_batchnorm2d_fold(rn_ctx *ctx, const float *weight, const float *bi
 typedef struct rn_epilogue {
     const float *scale;    /* per out-channel multiplier, NULL = 1 */
     const float *shift;    /* per out-channel addend,     NULL = 0 */
-    const float *residual; /* NHWC tensor of the output's shape added after scale/shift, NULL = none */
+    const void *residual;  /* NHWC tensor of the output's shape and element type, added after
+                              scale/shift; NULL = none */
     int relu;              /* apply max(x, 0) last */
 } rn_epilogue;
 
@@ -180,6 +184,37 @@ RN_API int rn_conv2d_nhwc_forward(rn_ctx *ctx, const float *inp, float *out,
                                   uint64_t out_channels, uint64_t H, uint64_t W,
                                   const rn_epilogue *epilogue /* nullable */);
 
+/* ---- element-type tagged engine entry points (bf16 storage, fp32 accumulate) ---------
+ * The fp32 functions above are the dtype == RN_DTYPE_F32 case of these.  bf16 tensors
+ * are NHWC only, 16-byte aligned, convolution in_channels a multiple of 64 (or the
+ * small-Cin stem form reading an image that carries its own zero border).           */
+RN_API uint64_t rn_conv2d_packed_weight_numel_dt(int dtype, uint64_t in_channels,
+                                                 uint64_t out_channels, uint64_t kernel_size);
+/* fp32 OIHW weights (the weights_bin order) -> K-major panel of `dtype` */
+RN_API int rn_conv2d_pack_weight_dt(rn_ctx *ctx, int dtype, const float *weight_oihw, void *packed,
+                                    uint64_t in_channels, uint64_t out_channels,
+                                    uint64_t kernel_size);
+/* fp32 NCHW [B,C,H,W] -> `dtype` NHWC [B, H+2*border, W+2*border, Cpad], zeros in the border
+ * and in channels >= C */
+RN_API int rn_nchw_to_nhwc_pad_dt(rn_ctx *ctx, int dtype, const float *src, void *dst, uint64_t B,
+                                  uint64_t C, uint64_t H, uint64_t W, uint64_t Cpad,
+                                  uint64_t border);
+/* inp/packed_weight of `dtype`, out and epilogue->residual of `out_dtype` */
+RN_API int rn_conv2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void *inp,
+                                     void *out, const void *packed_weight, uint64_t kernel_size,
+                                     uint64_t stride, uint64_t padding, uint64_t h_out,
+                                     uint64_t w_out, uint64_t B, uint64_t in_channels,
+                                     uint64_t out_channels, uint64_t H, uint64_t W,
+                                     const rn_epilogue *epilogue /* nullable */);
+RN_API int rn_maxpool2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, const void *inp, void *out,
+                                        uint64_t kernel_size, uint64_t stride, uint64_t padding,
+                                        uint64_t h_out, uint64_t w_out, uint64_t B,
+                                        uint64_t channels, uint64_t H, uint64_t W);
+RN_API int rn_avgpool2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, const void *inp, void *out,
+                                        uint64_t kernel_size, uint64_t stride, uint64_t padding,
+                                        uint64_t h_out, uint64_t w_out, uint64_t B,
+                                        uint64_t channels, uint64_t H, uint64_t W);
+
 /* ---- model (main.cu driver) ---------------------------------------------- */
 /* arch: 50, 101 or 152 (block counts 3/4/6/3, 3/4/23/3, 3/8/36/3). */
 RN_API int rn_model_create(rn_ctx *ctx, rn_model **out, int arch);
@@ -189,6 +224,10 @@ RN_API int rn_model_set_tensor(rn_model *m, const char *key, const float *host_d
                                uint64_t numel);
 /* read every tensor from dir/<key> (the reference's weights_bin/ directory) */
 RN_API int rn_model_load_dir(rn_model *m, const char *weights_dir);
+/* storage type of activations and packed weights inside the model: RN_DTYPE_F32 (default)
+ * or RN_DTYPE_BF16 (fused mode only).  Input images and logits stay fp32.  Call before
+ * rn_model_finalize. */
+RN_API int rn_model_set_dtype(rn_model *m, int dtype);
 /* upload-side work done once: pack conv weights, fold batch-norms */
 RN_API int rn_model_finalize(rn_model *m);
 /* names of the tensors the loader expects, one per call; returns NULL past the end */

@@ -17,6 +17,7 @@ RN_OK = 0
 RN_ERR_INVALID, RN_ERR_HIP, RN_ERR_IO, RN_ERR_NOMEM, RN_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
 RN_LAYOUT_NCHW, RN_LAYOUT_NHWC = 0, 1
 RN_FWD_REFERENCE_OPS, RN_FWD_FUSED = 0, 1
+RN_DTYPE_F32, RN_DTYPE_BF16 = 0, 1
 
 u64 = c_uint64
 fptr = c_void_p  # device pointers travel as plain addresses
@@ -73,7 +74,15 @@ SIGNATURES = {
     "rn_batchnorm2d_fold": (c_int, [c_void_p] + [fptr] * 6 + [u64]),
     "rn_conv2d_nhwc_forward": (c_int, [c_void_p, fptr, fptr, fptr] + [u64] * 10
                                + [POINTER(Epilogue)]),
+    "rn_conv2d_packed_weight_numel_dt": (u64, [c_int, u64, u64, u64]),
+    "rn_conv2d_pack_weight_dt": (c_int, [c_void_p, c_int, fptr, fptr, u64, u64, u64]),
+    "rn_nchw_to_nhwc_pad_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 6),
+    "rn_conv2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, c_int, fptr, fptr, fptr] + [u64] * 10
+                                  + [POINTER(Epilogue)]),
+    "rn_maxpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),
+    "rn_avgpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),
     "rn_model_create": (c_int, [c_void_p, POINTER(c_void_p), c_int]),
+    "rn_model_set_dtype": (c_int, [c_void_p, c_int]),
     "rn_model_destroy": (c_int, [c_void_p]),
     "rn_model_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, u64]),
     "rn_model_load_dir": (c_int, [c_void_p, c_char_p]),

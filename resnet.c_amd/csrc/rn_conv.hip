@@ -52,29 +52,45 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmParams {
-    const float *in;
-    const float *w;
-    float *out;
+    const void *in;
+    const void *w;
+    void *out;
     const float *scale;
     const float *shift;
-    const float *residual;
+    const void *residual;  // element type of the output
     int relu;
-    int H, W, Cs;  // input height, width, floats per input pixel
+    int H, W, Cs;  // input height, width, elements per input pixel
     int Ho, Wo, Cout;
     int KH, KW;  // taps walked by the K loop (small-Cin form: KW = 1)
     int stride, pad;
-    int cseg;      // 32-float segments per tap
-    int chunk_dw;  // small-Cin form: chunk c of a segment is pixel iw + c
-    int M;         // B * Ho * Wo
-    int Ktot;      // packed weight row length = KH * KW * cseg * 32
-    int nk;        // K tiles
+    int cseg;       // 128-byte segments per tap
+    int chunk_dw;   // small-Cin form: pixels per 16-byte chunk (0 otherwise)
+    int c4_chunks;  // small-Cin form: chunks of a segment that carry real taps
+    int M;          // B * Ho * Wo
+    int Ktot;       // packed weight row length in elements
+    int nk;         // K tiles
     int tiles_n;
     int HoWo;
     unsigned mul_hw, shr_hw, mul_w, shr_w;  // n / d == umulhi(n, mul) >> shr for n < 2^31
     int in_bytes, w_bytes;
 };
 
-constexpr int BK = 32;
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+
+// K tile = one 128-byte row segment: 32 fp32 or 64 bf16 elements; 16-byte chunk = 4 / 8
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr int BKE = 32, CH = 4;
+};
+template <>
+struct Elem<bf16_t> {
+    static constexpr int BKE = 64, CH = 8;
+};
+
+constexpr int ROW_FLOATS = 32;  // LDS row = 128 bytes, addressed as 32 dwords
 
 __device__ __forceinline__ float finish_nores(float v, float sc, float sh, bool has_scale,
                                               bool has_shift, int relu)
@@ -87,14 +103,67 @@ __device__ __forceinline__ float finish_nores(float v, float sc, float sh, bool 
     return relu ? fmaxf(v, 0.f) : v;
 }
 
-template <int BM, int BN>
+// EPT consecutive output elements of one row: load (residual) / store as one 16-byte access
+template <typename TO>
+struct OutVec;
+template <>
+struct OutVec<float> {
+    static constexpr int EPT = 4;
+    static __device__ __forceinline__ void load(const void *base, size_t idx, float (&v)[4])
+    {
+        const float4 x = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + idx);
+        v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w;
+    }
+    static __device__ __forceinline__ void store(void *base, size_t idx, const float (&v)[4])
+    {
+        *reinterpret_cast<float4 *>(static_cast<float *>(base) + idx) =
+            make_float4(v[0], v[1], v[2], v[3]);
+    }
+    static __device__ __forceinline__ float load1(const void *base, size_t idx)
+    {
+        return static_cast<const float *>(base)[idx];
+    }
+    static __device__ __forceinline__ void store1(void *base, size_t idx, float v)
+    {
+        static_cast<float *>(base)[idx] = v;
+    }
+};
+template <>
+struct OutVec<bf16_t> {
+    static constexpr int EPT = 8;
+    static __device__ __forceinline__ void load(const void *base, size_t idx, float (&v)[8])
+    {
+        const bf16x8 x = *reinterpret_cast<const bf16x8 *>(static_cast<const bf16_t *>(base) + idx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+    }
+    static __device__ __forceinline__ void store(void *base, size_t idx, const float (&v)[8])
+    {
+        bf16x8 x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (bf16_t)v[j];  // round to nearest even
+        *reinterpret_cast<bf16x8 *>(static_cast<bf16_t *>(base) + idx) = x;
+    }
+    static __device__ __forceinline__ float load1(const void *base, size_t idx)
+    {
+        return (float)static_cast<const bf16_t *>(base)[idx];
+    }
+    static __device__ __forceinline__ void store1(void *base, size_t idx, float v)
+    {
+        static_cast<bf16_t *>(base)[idx] = (bf16_t)v;
+    }
+};
+
+// T: element type of activations and weights; TO: element type of the output (and residual)
+template <typename T, typename TO, int BM, int BN>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 {
+    constexpr int BKE = Elem<T>::BKE, CH = Elem<T>::CH, ES = (int)sizeof(T);
     constexpr int AP = BM / 32;  // A rows staged per thread
     constexpr int BP = BN / 32;
     constexpr int MI = BM / 64;  // 32x32 tiles per wave along M
     constexpr int NI = BN / 64;
-    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int STAGE = (BM + BN) * ROW_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
     // XCD-aware tile order (bijective for any grid size)
@@ -113,9 +182,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     // out-of-range offset into zeros, so a padded tap (or a row past M / Cout) costs
     // one select on the offset instead of a branch around the load.
     const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, p.in_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, p.w_bytes, 0x00020000);
     constexpr int kOob = (int)0x80000000;  // >= num_records for every tensor we accept
 
     // per staged A row: byte offset of tap (0,0) chunk c, and which taps are in bounds:
@@ -132,11 +201,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
             const int ih0 = oh * p.stride - p.pad;
             const int iw0 = ow * p.stride - p.pad;
             const int iwc = iw0 + c * p.chunk_dw;
-            a_off[j] = (((b * p.H + ih0) * p.W + iw0) * p.Cs + c * 4) * 4;
+            a_off[j] = (((b * p.H + ih0) * p.W + iw0) * p.Cs + c * CH) * ES;
             const int rlo = max(0, -ih0), rhi = min(p.KH, p.H - ih0);
             const int clo = max(0, -iwc), chi = min(p.KW, p.W - iwc);
             const int rm = rhi > rlo ? ((1 << rhi) - 1) & ~((1 << rlo) - 1) : 0;
-            const int cm = chi > clo ? ((1 << chi) - 1) & ~((1 << clo) - 1) : 0;
+            int cm = chi > clo ? ((1 << chi) - 1) & ~((1 << clo) - 1) : 0;
+            if (p.chunk_dw && c >= p.c4_chunks) cm = 0;  // chunk holds only zero-weight slots
             a_mask[j] = rm | (cm << 16);
         } else {
             a_off[j] = 0;
@@ -148,32 +218,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 #pragma unroll
     for (int j = 0; j < BP; ++j) {
         const int n = n0 + r0 + 32 * j;
-        b_off[j] = n < p.Cout ? (n * p.Ktot + c * 4) * 4 : kOob;
+        b_off[j] = n < p.Cout ? (n * p.Ktot + c * CH) * ES : kOob;
     }
 
-    float4 ra[AP], rb[BP];
+    u32x4 ra[AP], rb[BP];
     int kh = 0, kw = 0, cs = 0;  // K-loop position of the tile being LOADED (wave-uniform)
 
     auto load_tile = [&](int kt) {
         const int s_kh = __builtin_amdgcn_readfirstlane(kh);
         const int s_kw = __builtin_amdgcn_readfirstlane(kw);
         const int s_cs = __builtin_amdgcn_readfirstlane(cs);
-        const int toff = ((s_kh * p.W + s_kw) * p.Cs + s_cs * BK) * 4;
+        const int toff = ((s_kh * p.W + s_kw) * p.Cs + s_cs * BKE) * ES;
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
             const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
             const int voff = ok ? a_off[j] + toff : kOob;
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0);
-            ra[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
-                                __uint_as_float(v.w));
+            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0);
         }
-        const int soff = __builtin_amdgcn_readfirstlane(kt) * (BK * 4);
+        const int soff = __builtin_amdgcn_readfirstlane(kt) * 128;
 #pragma unroll
-        for (int j = 0; j < BP; ++j) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_off[j], soff, 0);
-            rb[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
-                                __uint_as_float(v.w));
-        }
+        for (int j = 0; j < BP; ++j)
+            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_off[j], soff, 0);
         // advance to the next tile: segment fastest, then kw, then kh
         if (++cs == p.cseg) {
             cs = 0;
@@ -186,18 +251,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 
     auto store_tile = [&](int buf) {
         float *As = lds + buf * STAGE;
-        float *Bs = As + BM * BK;
+        float *Bs = As + BM * ROW_FLOATS;
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
             const int row = r0 + 32 * j;
             const int pc = c ^ ((row >> 1) & 7);
-            *reinterpret_cast<float4 *>(As + row * BK + pc * 4) = ra[j];
+            *reinterpret_cast<u32x4 *>(As + row * ROW_FLOATS + pc * 4) = ra[j];
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
             const int row = r0 + 32 * j;
             const int pc = c ^ ((row >> 1) & 7);
-            *reinterpret_cast<float4 *>(Bs + row * BK + pc * 4) = rb[j];
+            *reinterpret_cast<u32x4 *>(Bs + row * ROW_FLOATS + pc * 4) = rb[j];
         }
     };
 
@@ -215,30 +280,35 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
             for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
     auto compute_tile = [&](int buf) {
-        const float *As = lds + buf * STAGE + (wr * (BM / 2) + li) * BK;
-        const float *Bs = lds + buf * STAGE + BM * BK + (wc * (BN / 2) + li) * BK;
+        const float *As = lds + buf * STAGE + (wr * (BM / 2) + li) * ROW_FLOATS;
+        const float *Bs = lds + buf * STAGE + BM * ROW_FLOATS + (wc * (BN / 2) + li) * ROW_FLOATS;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            // lane (li, lh) reads chunk 2*ks+lh of its rows: fp32 -> k = 8ks+4lh+{0..3},
+            // bf16 -> k = 16ks+8lh+{0..7} (exactly the operand map of the 32x32x16 MFMA)
             const int pc = ((2 * ks + lh) ^ sw) * 4;
-            float4 a[MI], b[NI];
+            u32x4 a[MI], b[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                a[mi] = *reinterpret_cast<const float4 *>(As + mi * 32 * BK + pc);
+                a[mi] = *reinterpret_cast<const u32x4 *>(As + mi * 32 * ROW_FLOATS + pc);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                b[ni] = *reinterpret_cast<const float4 *>(Bs + ni * 32 * BK + pc);
+                b[ni] = *reinterpret_cast<const u32x4 *>(Bs + ni * 32 * ROW_FLOATS + pc);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    acc[mi][ni] =
-                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] =
-                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] =
-                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] =
-                        __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+                    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                __uint_as_float(a[mi][j]), __uint_as_float(b[ni][j]), acc[mi][ni], 0,
+                                0, 0);
+                    } else {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]),
+                            acc[mi][ni], 0, 0, 0);
+                    }
                 }
         }
     };
@@ -255,10 +325,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     }
 
     // epilogue.  The accumulators go through LDS (free after the K loop) so that global
-    // traffic is row-contiguous float4: C/D map of the 32x32 MFMA is col = lane&31,
+    // traffic is row-contiguous 16-byte accesses: C/D map of the 32x32 MFMA is col = lane&31,
     // row = (e&3) + 8*(e>>2) + 4*(lane>>5); a ds_write_b32 of one register puts 32
     // consecutive columns of two rows, conflict-free.
-    float *Cs = lds;  // [BM][BN]
+    float *Cs = lds;  // [BM][BN] fp32
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -269,39 +339,37 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         }
     __syncthreads();
 
-    constexpr int C4 = BN / 4;        // float4 per tile row
-    constexpr int RPP = 256 / C4;     // tile rows per pass of the block
+    constexpr int EPT = OutVec<TO>::EPT;  // output elements per thread and pass (16 bytes)
+    constexpr int CV = BN / EPT;          // threads per tile row
+    constexpr int RPP = 256 / CV;         // tile rows per pass of the block
     constexpr int PASSES = BM / RPP;
-    const int c4 = t % C4, rr = t / C4;
-    const int n = n0 + c4 * 4;
+    const int cv = t % CV, rr = t / CV;
+    const int n = n0 + cv * EPT;
     if (n >= p.Cout) return;
-    const bool vec = (p.Cout & 3) == 0;  // then n + 3 < Cout and every row start is 16-B aligned
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (p.Cout % EPT) == 0;  // then n + EPT <= Cout and rows are 16-B aligned
+    float sc[EPT], sh[EPT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < EPT; ++j) {
+        sc[j] = 1.f;
+        sh[j] = 0.f;
         if (n + j < p.Cout) {
             if (p.scale) sc[j] = p.scale[n + j];
             if (p.shift) sh[j] = p.shift[n + j];
         }
     }
     const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
-    auto finish = [&](float v, int j, float res) {
-        if (has_scale) {
-            v = fmaf(v, sc[j], sh[j]);
-        } else if (has_shift) {
-            v += sh[j];
-        }
-        v += res;
-        return p.relu ? fmaxf(v, 0.f) : v;
-    };
     if (vec) {
-        float4 res[PASSES];
+        float res[PASSES][EPT];
         if (p.residual) {
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
                 const int m = m0 + rr + ps * RPP;
-                res[ps] = m < p.M ? *reinterpret_cast<const float4 *>(p.residual + (size_t)m * p.Cout + n)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < p.M) {
+                    OutVec<TO>::load(p.residual, (size_t)m * p.Cout + n, res[ps]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EPT; ++j) res[ps][j] = 0.f;
+                }
             }
         }
 #pragma unroll
@@ -309,33 +377,51 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
             const int row = rr + ps * RPP;
             const int m = m0 + row;
             if (m >= p.M) continue;
-            float4 v = *reinterpret_cast<const float4 *>(Cs + row * BN + c4 * 4);
-            const float4 r = p.residual ? res[ps] : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p.residual) {
-                v.x = finish(v.x, 0, r.x);
-                v.y = finish(v.y, 1, r.y);
-                v.z = finish(v.z, 2, r.z);
-                v.w = finish(v.w, 3, r.w);
-            } else {
-                // no "+ 0.f": keeps -0.0 results of the plain convolution bit-exact
-                v.x = finish_nores(v.x, sc[0], sh[0], has_scale, has_shift, p.relu);
-                v.y = finish_nores(v.y, sc[1], sh[1], has_scale, has_shift, p.relu);
-                v.z = finish_nores(v.z, sc[2], sh[2], has_scale, has_shift, p.relu);
-                v.w = finish_nores(v.w, sc[3], sh[3], has_scale, has_shift, p.relu);
+            float v[EPT];
+#pragma unroll
+            for (int j4 = 0; j4 < EPT / 4; ++j4) {
+                const float4 x = *reinterpret_cast<const float4 *>(Cs + row * BN + cv * EPT + 4 * j4);
+                v[4 * j4] = x.x, v[4 * j4 + 1] = x.y, v[4 * j4 + 2] = x.z, v[4 * j4 + 3] = x.w;
             }
-            *reinterpret_cast<float4 *>(p.out + (size_t)m * p.Cout + n) = v;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                if (p.residual) {
+                    float y = v[j];
+                    if (has_scale) {
+                        y = fmaf(y, sc[j], sh[j]);
+                    } else if (has_shift) {
+                        y += sh[j];
+                    }
+                    y += res[ps][j];
+                    v[j] = p.relu ? fmaxf(y, 0.f) : y;
+                } else {
+                    // no "+ 0.f": keeps -0.0 results of the plain convolution bit-exact
+                    v[j] = finish_nores(v[j], sc[j], sh[j], has_scale, has_shift, p.relu);
+                }
+            }
+            OutVec<TO>::store(p.out, (size_t)m * p.Cout + n, v);
         }
     } else {
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = rr + ps * RPP;
             const int m = m0 + row;
             if (m >= p.M) continue;
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < EPT; ++j) {
                 if (n + j >= p.Cout) break;
                 const size_t o = (size_t)m * p.Cout + n + j;
-                const float v = Cs[row * BN + c4 * 4 + j];
-                p.out[o] = p.residual ? finish(v, j, p.residual[o])
-                                      : finish_nores(v, sc[j], sh[j], has_scale, has_shift, p.relu);
+                float y = Cs[row * BN + cv * EPT + j];
+                if (p.residual) {
+                    if (has_scale) {
+                        y = fmaf(y, sc[j], sh[j]);
+                    } else if (has_shift) {
+                        y += sh[j];
+                    }
+                    y += OutVec<TO>::load1(p.residual, o);
+                    y = p.relu ? fmaxf(y, 0.f) : y;
+                } else {
+                    y = finish_nores(y, sc[j], sh[j], has_scale, has_shift, p.relu);
+                }
+                OutVec<TO>::store1(p.out, o, y);
             }
         }
     }
@@ -429,12 +515,29 @@ void fast_div(unsigned d, unsigned *mul, unsigned *shr)
     *shr = p - 32;
 }
 
-// GEMM launch on NHWC data with packed weights.  Caller has checked eligibility.
-int launch_gemm(rn_ctx *ctx, const float *inp, float *out, const float *packed, uint64_t k,
-                uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out, uint64_t B,
-                uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W, const rn_epilogue *ep,
-                const char *what)
+template <typename T, typename TO>
+void launch_tiles(rn_ctx *ctx, const GemmParams &p, int BMsel, int BNsel, unsigned grid)
 {
+    dim3 g(grid), blk(256);
+    if (BMsel == 128 && BNsel == 128)
+        conv_gemm_kernel<T, TO, 128, 128><<<g, blk, 0, ctx->stream>>>(p);
+    else if (BMsel == 128 && BNsel == 64)
+        conv_gemm_kernel<T, TO, 128, 64><<<g, blk, 0, ctx->stream>>>(p);
+    else if (BMsel == 64 && BNsel == 128)
+        conv_gemm_kernel<T, TO, 64, 128><<<g, blk, 0, ctx->stream>>>(p);
+    else
+        conv_gemm_kernel<T, TO, 64, 64><<<g, blk, 0, ctx->stream>>>(p);
+}
+
+// GEMM launch on NHWC data with packed weights.  Caller has checked eligibility.
+// dt_in: element type of activations and weights; dt_out: of the output and the residual.
+int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, const void *packed,
+                uint64_t k, uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out,
+                uint64_t B, uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W,
+                const rn_epilogue *ep, const char *what)
+{
+    const int es = dt_in == RN_DTYPE_BF16 ? 2 : 4;
+    const int bke = 128 / es;
     GemmParams p;
     p.in = inp;
     p.w = packed;
@@ -454,21 +557,22 @@ int launch_gemm(rn_ctx *ctx, const float *inp, float *out, const float *packed, 
     p.KW = c4 ? 1 : (int)k;
     p.stride = (int)stride;
     p.pad = (int)pad;
-    p.cseg = c4 ? 1 : (int)(Cin / 32);
-    p.chunk_dw = c4 ? 1 : 0;
+    p.cseg = c4 ? 1 : (int)(Cin / bke);
+    p.chunk_dw = c4 ? 16 / (4 * es) : 0;  // pixels of a 4-channel image per 16-byte chunk
+    p.c4_chunks = c4 ? (int)rn_ceil_div(k, p.chunk_dw) : 0;
     p.M = (int)(B * h_out * w_out);
     p.nk = p.KH * p.KW * p.cseg;
-    p.Ktot = p.nk * BK;
+    p.Ktot = p.nk * bke;
     p.HoWo = p.Ho * p.Wo;
     fast_div((unsigned)p.HoWo, &p.mul_hw, &p.shr_hw);
     fast_div((unsigned)p.Wo, &p.mul_w, &p.shr_w);
-    p.in_bytes = (int)(B * H * W * (uint64_t)p.Cs * 4);
-    p.w_bytes = (int)(Cout * (uint64_t)p.Ktot * 4);
+    p.in_bytes = (int)(B * H * W * (uint64_t)p.Cs * es);
+    p.w_bytes = (int)(Cout * (uint64_t)p.Ktot * es);
 
     // tile choice: the contraction is matrix-core bound, so a launch takes about
     // ceil(tiles / 256 CUs) rounds of one tile's MFMA time; pick the candidate with the
     // least (rounds * tile area / relative tile efficiency), i.e. the least padded,
-    // best balanced cover of the 256 CUs.
+    // best balanced cover of the 256 CUs.  rn_model_tune measures instead of guessing.
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     static const double cand_eff[4] = {1.00, 0.94, 0.94, 0.86};
     int BMsel = 128, BNsel = 128;
@@ -494,15 +598,15 @@ int launch_gemm(rn_ctx *ctx, const float *inp, float *out, const float *packed, 
     p.tiles_n = (int)tiles_n;
     const uint64_t grid = tiles_m * tiles_n;
     RN_REQUIRE(ctx, fits_i32(grid), "too many tiles");
-    dim3 g((unsigned)grid), blk(256);
-    if (BMsel == 128 && BNsel == 128)
-        conv_gemm_kernel<128, 128><<<g, blk, 0, ctx->stream>>>(p);
-    else if (BMsel == 128 && BNsel == 64)
-        conv_gemm_kernel<128, 64><<<g, blk, 0, ctx->stream>>>(p);
-    else if (BMsel == 64 && BNsel == 128)
-        conv_gemm_kernel<64, 128><<<g, blk, 0, ctx->stream>>>(p);
+    if (dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)
+        launch_tiles<float, float>(ctx, p, BMsel, BNsel, (unsigned)grid);
+    else if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_BF16)
+        launch_tiles<bf16_t, bf16_t>(ctx, p, BMsel, BNsel, (unsigned)grid);
+    else if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_F32)
+        launch_tiles<bf16_t, float>(ctx, p, BMsel, BNsel, (unsigned)grid);
     else
-        conv_gemm_kernel<64, 64><<<g, blk, 0, ctx->stream>>>(p);
+        return rn_set_error(ctx, RN_ERR_UNSUPPORTED, "%s: dtype combination %d -> %d", what, dt_in,
+                            dt_out);
     return rn_after_launch(ctx, what);
 }
 
@@ -517,7 +621,7 @@ int launch_direct(rn_ctx *ctx, const float *inp, float *out, const float *w, uin
     p.out = out;
     p.scale = ep ? ep->scale : nullptr;
     p.shift = ep ? ep->shift : nullptr;
-    p.residual = ep ? ep->residual : nullptr;
+    p.residual = ep ? static_cast<const float *>(ep->residual) : nullptr;
     p.relu = ep ? ep->relu : 0;
     p.k = (int)k;
     p.stride = (int)stride;
@@ -581,8 +685,9 @@ int rn_conv2d_nhwc_forward(rn_ctx *ctx, const float *inp, float *out, const floa
     if (gemm_eligible(inp, out, packed_weight, in_channels, kernel_size,
                       B * H * W * rn_conv2d_input_channels(in_channels),
                       rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size))) {
-        return launch_gemm(ctx, inp, out, packed_weight, kernel_size, stride, padding, h_out, w_out,
-                           B, in_channels, out_channels, H, W, epilogue, "rn_conv2d_nhwc_forward");
+        return launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, inp, out, packed_weight, kernel_size,
+                           stride, padding, h_out, w_out, B, in_channels, out_channels, H, W,
+                           epilogue, "rn_conv2d_nhwc_forward");
     }
     const bool c4 = rn_conv_is_c4(in_channels, kernel_size);
     return launch_direct(ctx, inp, out, packed_weight, kernel_size, stride, padding, h_out, w_out,
@@ -617,8 +722,8 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
     RN_TRY(rn_scratch(ctx, 1, wn * sizeof(float), &wp));
     RN_TRY(rn_conv2d_pack_weight(ctx, weight, (float *)wp, in_channels, out_channels, kernel_size));
     if (ctx->layout == RN_LAYOUT_NHWC) {
-        return launch_gemm(ctx, inp, out, (const float *)wp, kernel_size, stride, padding, h_out,
-                           w_out, B, in_channels, out_channels, H, W, nullptr,
+        return launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, inp, out, wp, kernel_size, stride,
+                           padding, h_out, w_out, B, in_channels, out_channels, H, W, nullptr,
                            "rn_conv2d_forward(nhwc)");
     }
     // NCHW caller: transpose in, contract, transpose out
@@ -631,10 +736,52 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
     } else {
         RN_TRY(rn_nchw_to_nhwc(ctx, inp, (float *)xin, B, in_channels, H, W));
     }
-    RN_TRY(launch_gemm(ctx, (const float *)xin, (float *)xout, (const float *)wp, kernel_size,
-                       stride, padding, h_out, w_out, B, in_channels, out_channels, H, W, nullptr,
+    RN_TRY(launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, xin, xout, wp, kernel_size, stride, padding,
+                       h_out, w_out, B, in_channels, out_channels, H, W, nullptr,
                        "rn_conv2d_forward(gemm)"));
     return rn_nhwc_to_nchw(ctx, (const float *)xout, out, B, out_channels, h_out, w_out);
+}
+
+int rn_conv2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void *inp, void *out,
+                              const void *packed_weight, uint64_t kernel_size, uint64_t stride,
+                              uint64_t padding, uint64_t h_out, uint64_t w_out, uint64_t B,
+                              uint64_t in_channels, uint64_t out_channels, uint64_t H, uint64_t W,
+                              const rn_epilogue *epilogue)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (dtype == RN_DTYPE_F32) {
+        RN_REQUIRE(ctx, out_dtype == RN_DTYPE_F32, "fp32 input implies fp32 output");
+        return rn_conv2d_nhwc_forward(ctx, (const float *)inp, (float *)out,
+                                      (const float *)packed_weight, kernel_size, stride, padding,
+                                      h_out, w_out, B, in_channels, out_channels, H, W, epilogue);
+    }
+    RN_REQUIRE(ctx, dtype == RN_DTYPE_BF16, "unknown dtype");
+    if (B * out_channels * h_out * w_out == 0) return RN_OK;
+    RN_REQUIRE(ctx, inp && out && packed_weight && inp != out, "null or aliased tensor");
+    RN_REQUIRE(ctx, kernel_size >= 1 && kernel_size <= 15 && stride >= 1 && stride < (1u << 12) &&
+                        padding < (1u << 12),
+               "kernel_size / stride / padding out of range");
+    const bool c4 = rn_conv_is_c4(in_channels, kernel_size);
+    const uint64_t cs = c4 ? 4 : in_channels;
+    if (c4) {
+        // two 4-channel pixels per 16-byte chunk: the image must carry its own zero border
+        RN_REQUIRE(ctx, padding == 0 && stride % 2 == 0 && W % 2 == 0,
+                   "bf16 small-Cin form needs a physically padded image, even stride and width");
+    } else if (in_channels % 64 != 0) {
+        return rn_set_error(ctx, RN_ERR_UNSUPPORTED,
+                            "bf16 convolution needs in_channels %% 64 == 0 (got %llu)",
+                            (unsigned long long)in_channels);
+    }
+    const uint64_t ktot = c4 ? kernel_size * 64 : kernel_size * kernel_size * in_channels;
+    RN_REQUIRE(ctx, B * H * W * cs < (1ull << 30) && out_channels * ktot < (1ull << 30) &&
+                        fits_i32(B * h_out * w_out * out_channels),
+               "tensor too large");
+    RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out) |
+                      reinterpret_cast<uintptr_t>(packed_weight)) & 15) == 0,
+               "bf16 tensors must be 16-byte aligned");
+    return launch_gemm(ctx, RN_DTYPE_BF16, out_dtype, inp, out, packed_weight, kernel_size, stride,
+                       padding, h_out, w_out, B, in_channels, out_channels, H, W, epilogue,
+                       "rn_conv2d_nhwc_forward_dt");
 }
 
 int rn_linear_forward(rn_ctx *ctx, const float *inp, float *out, const float *weight,
@@ -652,8 +799,8 @@ int rn_linear_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
     // W is [out][in] row-major == the K-major panel of a 1x1 convolution on a 1x1 image
     if (in_features % 32 == 0 &&
         gemm_eligible(inp, out, weight, in_features, 1, B * in_features, out_features * in_features)) {
-        return launch_gemm(ctx, inp, out, weight, 1, 1, 0, 1, 1, B, in_features, out_features, 1, 1,
-                           &ep, "rn_linear_forward");
+        return launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, inp, out, weight, 1, 1, 0, 1, 1, B,
+                           in_features, out_features, 1, 1, &ep, "rn_linear_forward");
     }
     return launch_direct(ctx, inp, out, weight, 1, 1, 0, 1, 1, B, in_features, in_features,
                          out_features, 1, 1, 1, 0, &ep, "rn_linear_forward(direct)");

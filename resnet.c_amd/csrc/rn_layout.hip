@@ -99,6 +99,68 @@ __global__ __launch_bounds__(256) void pack_weight_c4_kernel(const float *__rest
     }
 }
 
+typedef __bf16 bf16_t;
+
+// OIHW fp32 -> bf16 [Cout][kh][kw][Cin]
+__global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float *__restrict__ w,
+                                                               bf16_t *__restrict__ packed,
+                                                               uint32_t Cin, uint32_t k,
+                                                               uint64_t total)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    const uint32_t kk = k * k;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+        const uint32_t ic = (uint32_t)(i % Cin);
+        uint64_t r = i / Cin;
+        const uint32_t tap = (uint32_t)(r % kk);
+        const uint64_t oc = r / kk;
+        packed[i] = (bf16_t)w[(oc * Cin + ic) * kk + tap];
+    }
+}
+
+// small-Cin bf16 panel: [Cout][kh][16 kw slots][4 channel slots] (one 128-byte K segment
+// = 16 consecutive pixels of a 4-channel bf16 image)
+__global__ __launch_bounds__(256) void pack_weight_c4_bf16_kernel(const float *__restrict__ w,
+                                                                  bf16_t *__restrict__ packed,
+                                                                  uint32_t Cin, uint32_t k,
+                                                                  uint64_t total)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+        const uint32_t ic = (uint32_t)(i & 3);
+        const uint32_t kw = (uint32_t)((i >> 2) & 15);
+        const uint64_t r = i >> 6;
+        const uint32_t kh = (uint32_t)(r % k);
+        const uint64_t oc = r / k;
+        packed[i] = (bf16_t)((ic < Cin && kw < k) ? w[((oc * Cin + ic) * k + kh) * k + kw] : 0.f);
+    }
+}
+
+// fp32 NCHW -> T NHWC [B][H+2b][W+2b][Cpad] with a zero border of b pixels
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_border_kernel(const float *__restrict__ src,
+                                                                  T *__restrict__ dst, uint32_t C,
+                                                                  uint32_t H, uint32_t W,
+                                                                  uint32_t Cpad, uint32_t border,
+                                                                  uint64_t total)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    const uint32_t Hp = H + 2 * border, Wp = W + 2 * border;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+        const uint32_t c = (uint32_t)(i % Cpad);
+        uint64_t p = i / Cpad;
+        const uint32_t wp = (uint32_t)(p % Wp);
+        p /= Wp;
+        const uint32_t hp = (uint32_t)(p % Hp);
+        const uint64_t b = p / Hp;
+        const int h = (int)hp - (int)border, w = (int)wp - (int)border;
+        float v = 0.f;
+        if (c < C && h >= 0 && h < (int)H && w >= 0 && w < (int)W)
+            v = src[((b * C + c) * H + h) * W + w];
+        dst[i] = (T)v;
+    }
+}
+
 }  // namespace
 
 bool rn_conv_is_c4(uint64_t Cin, uint64_t k) { return Cin <= 4 && k <= 8; }
@@ -133,6 +195,64 @@ int rn_conv2d_pack_weight(rn_ctx *ctx, const float *weight_oihw, float *packed,
             weight_oihw, packed, (uint32_t)in_channels, (uint32_t)kernel_size, total);
     }
     return rn_after_launch(ctx, "rn_conv2d_pack_weight");
+}
+
+uint64_t rn_conv2d_packed_weight_numel_dt(int dtype, uint64_t in_channels, uint64_t out_channels,
+                                          uint64_t kernel_size)
+{
+    if (dtype == RN_DTYPE_F32)
+        return rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size);
+    if (rn_conv_is_c4(in_channels, kernel_size)) return out_channels * kernel_size * 64;
+    return out_channels * kernel_size * kernel_size * in_channels;
+}
+
+int rn_conv2d_pack_weight_dt(rn_ctx *ctx, int dtype, const float *weight_oihw, void *packed,
+                             uint64_t in_channels, uint64_t out_channels, uint64_t kernel_size)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (dtype == RN_DTYPE_F32)
+        return rn_conv2d_pack_weight(ctx, weight_oihw, (float *)packed, in_channels, out_channels,
+                                     kernel_size);
+    RN_REQUIRE(ctx, dtype == RN_DTYPE_BF16, "unknown dtype");
+    const uint64_t total =
+        rn_conv2d_packed_weight_numel_dt(dtype, in_channels, out_channels, kernel_size);
+    if (total == 0) return RN_OK;
+    RN_REQUIRE(ctx, weight_oihw && packed, "null tensor");
+    RN_REQUIRE(ctx, in_channels < (1u << 30) && kernel_size < (1u << 15), "dimension too large");
+    if (rn_conv_is_c4(in_channels, kernel_size)) {
+        pack_weight_c4_bf16_kernel<<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
+            weight_oihw, (bf16_t *)packed, (uint32_t)in_channels, (uint32_t)kernel_size, total);
+    } else {
+        pack_weight_bf16_kernel<<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
+            weight_oihw, (bf16_t *)packed, (uint32_t)in_channels, (uint32_t)kernel_size, total);
+    }
+    return rn_after_launch(ctx, "rn_conv2d_pack_weight_dt");
+}
+
+int rn_nchw_to_nhwc_pad_dt(rn_ctx *ctx, int dtype, const float *src, void *dst, uint64_t B,
+                           uint64_t C, uint64_t H, uint64_t W, uint64_t Cpad, uint64_t border)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (dtype == RN_DTYPE_F32 && border == 0)
+        return rn_nchw_to_nhwc_pad(ctx, src, (float *)dst, B, C, H, W, Cpad);
+    const uint64_t total = B * (H + 2 * border) * (W + 2 * border) * Cpad;
+    if (total == 0) return RN_OK;
+    RN_REQUIRE(ctx, src && dst && (const void *)src != dst, "null or aliased tensor");
+    RN_REQUIRE(ctx, Cpad >= C && C >= 1, "Cpad must be >= C >= 1");
+    RN_REQUIRE(ctx, H < (1u << 20) && W < (1u << 20) && Cpad < (1u << 20) && border < (1u << 10),
+               "dimension too large");
+    if (dtype == RN_DTYPE_BF16) {
+        nchw_to_nhwc_border_kernel<bf16_t><<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
+            src, (bf16_t *)dst, (uint32_t)C, (uint32_t)H, (uint32_t)W, (uint32_t)Cpad,
+            (uint32_t)border, total);
+    } else if (dtype == RN_DTYPE_F32) {
+        nchw_to_nhwc_border_kernel<float><<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
+            src, (float *)dst, (uint32_t)C, (uint32_t)H, (uint32_t)W, (uint32_t)Cpad,
+            (uint32_t)border, total);
+    } else {
+        return rn_set_error(ctx, RN_ERR_INVALID, "unknown dtype %d", dtype);
+    }
+    return rn_after_launch(ctx, "rn_nchw_to_nhwc_pad_dt");
 }
 
 static int transpose_launch(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t R,

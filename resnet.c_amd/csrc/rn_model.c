@@ -41,7 +41,7 @@ typedef struct {
     char name[RN_MAX_KEY];
     uint64_t cin, cout, k, stride, pad;
     int w, bn_w, bn_b, bn_m, bn_v; /* indices into params */
-    float *packed;                 /* K-major panel */
+    void *packed;                  /* K-major panel, model dtype */
     float *scale, *shift;          /* folded batch-norm */
     int tile;                      /* tuned contraction tile (0 = per-launch choice) */
 } rn_conv;
@@ -61,9 +61,9 @@ typedef struct {
 
 typedef struct {
     int conv;
-    const float *x;
-    float *y;
-    uint64_t B, H, W;
+    const void *x;
+    void *y;
+    uint64_t B, H, W, pad;
     rn_epilogue ep;
     int has_ep;
 } rn_conv_call;
@@ -80,6 +80,8 @@ struct rn_model {
     int n_blocks;
     int fc_w, fc_b;
     int finalized;
+    int dtype;        /* storage type of activations and packed weights */
+    void *fc_packed;  /* fc.weight in the model dtype (bf16 models only) */
     /* activation arenas, sized for batch_cap images */
     uint64_t batch_cap;
     float *x4, *p0, *p1, *dsb, *t1, *t2, *pooled;
@@ -240,6 +242,7 @@ int rn_model_destroy(rn_model *m)
             rn_free(m->ctx, m->convs[c].shift);
         }
     }
+    rn_free(m->ctx, m->fc_packed);
     free_acts(m);
     free_prof(m);
     free(m->params);
@@ -301,6 +304,28 @@ int rn_model_load_dir(rn_model *m, const char *weights_dir)
     return RN_OK;
 }
 
+static uint64_t elem_size(const rn_model *m) { return m->dtype == RN_DTYPE_BF16 ? 2 : 4; }
+
+int rn_model_set_dtype(rn_model *m, int dtype)
+{
+    int c;
+    if (!m || (dtype != RN_DTYPE_F32 && dtype != RN_DTYPE_BF16)) return RN_ERR_INVALID;
+    if (dtype == m->dtype) return RN_OK;
+    /* packed panels and arenas depend on the element size: drop them */
+    for (c = 0; c < m->n_convs; ++c) {
+        rn_free(m->ctx, m->convs[c].packed);
+        m->convs[c].packed = NULL;
+        m->convs[c].tile = 0;
+    }
+    rn_free(m->ctx, m->fc_packed);
+    m->fc_packed = NULL;
+    free_acts(m);
+    m->dtype = dtype;
+    m->finalized = 0;
+    m->tuned_B = 0;
+    return RN_OK;
+}
+
 int rn_model_finalize(rn_model *m)
 {
     uint64_t i;
@@ -311,21 +336,33 @@ int rn_model_finalize(rn_model *m)
     }
     for (c = 0; c < m->n_convs; ++c) {
         rn_conv *cv = &m->convs[c];
-        const uint64_t pn = rn_conv2d_packed_weight_numel(cv->cin, cv->cout, cv->k);
+        const uint64_t pn = rn_conv2d_packed_weight_numel_dt(m->dtype, cv->cin, cv->cout, cv->k);
         if (!cv->packed) {
-            st = rn_malloc(m->ctx, (void **)&cv->packed, pn * sizeof(float));
+            st = rn_malloc(m->ctx, &cv->packed, pn * elem_size(m));
             if (st != RN_OK) return st;
+        }
+        if (!cv->scale) {
             st = rn_malloc(m->ctx, (void **)&cv->scale, cv->cout * sizeof(float));
             if (st != RN_OK) return st;
             st = rn_malloc(m->ctx, (void **)&cv->shift, cv->cout * sizeof(float));
             if (st != RN_OK) return st;
         }
-        st = rn_conv2d_pack_weight(m->ctx, m->params[cv->w].dev, cv->packed, cv->cin, cv->cout,
-                                   cv->k);
+        st = rn_conv2d_pack_weight_dt(m->ctx, m->dtype, m->params[cv->w].dev, cv->packed, cv->cin,
+                                      cv->cout, cv->k);
         if (st != RN_OK) return st;
         st = rn_batchnorm2d_fold(m->ctx, m->params[cv->bn_w].dev, m->params[cv->bn_b].dev,
                                  m->params[cv->bn_m].dev, m->params[cv->bn_v].dev, cv->scale,
                                  cv->shift, cv->cout);
+        if (st != RN_OK) return st;
+    }
+    if (m->dtype != RN_DTYPE_F32) {
+        /* fc.weight [1000][2048] is a 1x1 convolution panel: same packer, k = 1 */
+        if (!m->fc_packed) {
+            st = rn_malloc(m->ctx, &m->fc_packed, (uint64_t)RN_CLASSES * 2048 * elem_size(m));
+            if (st != RN_OK) return st;
+        }
+        st = rn_conv2d_pack_weight_dt(m->ctx, m->dtype, m->params[m->fc_w].dev, m->fc_packed, 2048,
+                                      RN_CLASSES, 1);
         if (st != RN_OK) return st;
     }
     st = rn_sync(m->ctx);
@@ -335,7 +372,7 @@ int rn_model_finalize(rn_model *m)
 }
 
 /* per-image element counts of the arenas (see the header comment) */
-#define X4_PER_IMG ((uint64_t)224 * 224 * 4)
+#define X4_PER_IMG ((uint64_t)230 * 230 * 4) /* bf16 models keep a 3-pixel zero border */
 #define P_PER_IMG ((uint64_t)56 * 56 * 256) /* == 112*112*64, the stem output */
 #define T_PER_IMG ((uint64_t)56 * 56 * 128) /* layer2.0 conv1 output, the largest mid tensor */
 
@@ -344,19 +381,22 @@ static int ensure_acts(rn_model *m, uint64_t B)
     int st;
     if (B <= m->batch_cap) return RN_OK;
     free_acts(m);
-    st = rn_malloc(m->ctx, (void **)&m->x4, B * X4_PER_IMG * sizeof(float));
-    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->p0, B * P_PER_IMG * sizeof(float));
-    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->p1, B * P_PER_IMG * sizeof(float));
-    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->dsb, B * P_PER_IMG * sizeof(float));
-    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->t1, B * T_PER_IMG * sizeof(float));
-    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->t2, B * T_PER_IMG * sizeof(float));
-    if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->pooled, B * 2048 * sizeof(float));
+    {
+        const uint64_t es = elem_size(m);
+        st = rn_malloc(m->ctx, (void **)&m->x4, B * X4_PER_IMG * es);
+        if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->p0, B * P_PER_IMG * es);
+        if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->p1, B * P_PER_IMG * es);
+        if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->dsb, B * P_PER_IMG * es);
+        if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->t1, B * T_PER_IMG * es);
+        if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->t2, B * T_PER_IMG * es);
+        if (st == RN_OK) st = rn_malloc(m->ctx, (void **)&m->pooled, B * 2048 * es);
+    }
     if (st != RN_OK) {
         free_acts(m);
         return st;
     }
     m->batch_cap = B;
-    m->act_bytes = B * (X4_PER_IMG + 3 * P_PER_IMG + 2 * T_PER_IMG + 2048) * sizeof(float);
+    m->act_bytes = B * (X4_PER_IMG + 3 * P_PER_IMG + 2 * T_PER_IMG + 2048) * elem_size(m);
     return RN_OK;
 }
 
@@ -434,15 +474,19 @@ int rn_model_profile_get(const rn_model *m, uint64_t index, const char **op_name
     } while (0)
 
 /* ---- ops with profiling brackets --------------------------------------- */
-static int op_conv(rn_model *m, const rn_conv *cv, const float *x, float *y, uint64_t B,
-                   uint64_t H, uint64_t W, const rn_epilogue *ep)
+/* pad_override >= 0 replaces the layer's padding (the bf16 stem reads an image that carries
+ * its own zero border: H, W are then the padded sizes and the padding is 0) */
+static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint64_t B, uint64_t H,
+                   uint64_t W, const rn_epilogue *ep, int64_t pad_override)
 {
-    const uint64_t ho = rn_conv_output_size(H, cv->k, cv->stride, cv->pad);
-    const uint64_t wo = rn_conv_output_size(W, cv->k, cv->stride, cv->pad);
+    const uint64_t pad = pad_override >= 0 ? (uint64_t)pad_override : cv->pad;
+    const uint64_t ho = rn_conv_output_size(H, cv->k, cv->stride, pad);
+    const uint64_t wo = rn_conv_output_size(W, cv->k, cv->stride, pad);
     const double M = (double)(B * ho * wo), K = (double)(cv->cin * cv->k * cv->k);
-    double bytes = 4.0 * ((double)(B * H * W * cv->cin) + K * (double)cv->cout +
-                          M * (double)cv->cout);
-    if (ep && ep->residual) bytes += 4.0 * M * (double)cv->cout;
+    const double es = (double)elem_size(m);
+    double bytes = es * ((double)(B * H * W * cv->cin) + K * (double)cv->cout +
+                         M * (double)cv->cout);
+    if (ep && ep->residual) bytes += es * M * (double)cv->cout;
     if (m->recording) {
         rn_conv_call *c = &m->calls[m->n_calls++];
         c->conv = (int)(cv - m->convs);
@@ -451,6 +495,7 @@ static int op_conv(rn_model *m, const rn_conv *cv, const float *x, float *y, uin
         c->B = B;
         c->H = H;
         c->W = W;
+        c->pad = pad;
         c->has_ep = ep != NULL;
         if (ep) c->ep = *ep;
     }
@@ -458,8 +503,9 @@ static int op_conv(rn_model *m, const rn_conv *cv, const float *x, float *y, uin
                    bytes));
     rn_ctx_set_conv_tile(m->ctx, (m->tuned_B == B && m->tuned_mode == m->cur_mode) ? cv->tile : 0);
     {
-        const int st = rn_conv2d_nhwc_forward(m->ctx, x, y, cv->packed, cv->k, cv->stride, cv->pad,
-                                              ho, wo, B, cv->cin, cv->cout, H, W, ep);
+        const int st = rn_conv2d_nhwc_forward_dt(m->ctx, m->dtype, m->dtype, x, y, cv->packed, cv->k,
+                                                 cv->stride, pad, ho, wo, B, cv->cin, cv->cout, H, W,
+                                                 ep);
         rn_ctx_set_conv_tile(m->ctx, 0);
         if (st != RN_OK) return st;
     }
@@ -503,29 +549,29 @@ static int block_forward(rn_model *m, const rn_block *b, const float *x, float *
         if (b->ds >= 0) {
             const rn_conv *cd = &m->convs[b->ds];
             ep.scale = cd->scale; ep.shift = cd->shift; ep.residual = NULL; ep.relu = 0;
-            TRY(op_conv(m, cd, x, m->dsb, B, h, w, &ep));
+            TRY(op_conv(m, cd, x, m->dsb, B, h, w, &ep, -1));
             shortcut = m->dsb;
         }
         ep.scale = c1->scale; ep.shift = c1->shift; ep.residual = NULL; ep.relu = 1;
-        TRY(op_conv(m, c1, x, m->t1, B, h, w, &ep));
+        TRY(op_conv(m, c1, x, m->t1, B, h, w, &ep, -1));
         ep.scale = c2->scale; ep.shift = c2->shift;
-        TRY(op_conv(m, c2, m->t1, m->t2, B, h, w, &ep));
+        TRY(op_conv(m, c2, m->t1, m->t2, B, h, w, &ep, -1));
         ep.scale = c3->scale; ep.shift = c3->shift; ep.residual = shortcut;
-        TRY(op_conv(m, c3, m->t2, y, B, ho, wo, &ep));
+        TRY(op_conv(m, c3, m->t2, y, B, ho, wo, &ep, -1));
     } else {
         if (b->ds >= 0) {
             const rn_conv *cd = &m->convs[b->ds];
-            TRY(op_conv(m, cd, x, m->dsb, B, h, w, NULL));
+            TRY(op_conv(m, cd, x, m->dsb, B, h, w, NULL, -1));
             TRY(op_bn(m, cd, m->dsb, B, ho * wo));
             shortcut = m->dsb;
         }
-        TRY(op_conv(m, c1, x, m->t1, B, h, w, NULL));
+        TRY(op_conv(m, c1, x, m->t1, B, h, w, NULL, -1));
         TRY(op_bn(m, c1, m->t1, B, h * w));
         TRY(op_relu(m, c1->name, m->t1, B * h * w * c1->cout));
-        TRY(op_conv(m, c2, m->t1, m->t2, B, h, w, NULL));
+        TRY(op_conv(m, c2, m->t1, m->t2, B, h, w, NULL, -1));
         TRY(op_bn(m, c2, m->t2, B, ho * wo));
         TRY(op_relu(m, c2->name, m->t2, B * ho * wo * c2->cout));
-        TRY(op_conv(m, c3, m->t2, y, B, ho, wo, NULL));
+        TRY(op_conv(m, c3, m->t2, y, B, ho, wo, NULL, -1));
         TRY(op_bn(m, c3, y, B, ho * wo));
         TRY(op_add(m, b->name, y, shortcut, B * ho * wo * c3->cout));
         TRY(op_relu(m, b->name, y, B * ho * wo * c3->cout));
@@ -544,6 +590,8 @@ int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *lo
     if (!m || !input_nchw || !logits || B == 0) return RN_ERR_INVALID;
     if (mode != RN_FWD_REFERENCE_OPS && mode != RN_FWD_FUSED) return RN_ERR_INVALID;
     if (!m->finalized) return RN_ERR_INVALID;
+    /* bf16 storage exists only with the fused epilogues (no standalone bf16 bn/relu/add) */
+    if (m->dtype != RN_DTYPE_F32 && mode != RN_FWD_FUSED) return RN_ERR_UNSUPPORTED;
     TRY(ensure_acts(m, B));
     m->n_prof = 0;
     m->cur_mode = mode;
@@ -552,27 +600,46 @@ int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *lo
     st = RN_OK;
     do {
 #define STEP(expr) if ((st = (expr)) != RN_OK) break
+        const double es = (double)elem_size(m);
+        const int bf16 = m->dtype == RN_DTYPE_BF16;
         stem = &m->convs[0];
-        STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0, 4.0 * (double)(B * 224 * 224 * 7)));
-        STEP(rn_nchw_to_nhwc_pad(m->ctx, input_nchw, m->x4, B, 3, H, W, 4));
-        STEP(prof_end(m));
-        ho = rn_conv_output_size(H, stem->k, stem->stride, stem->pad);
-        wo = rn_conv_output_size(W, stem->k, stem->stride, stem->pad);
-        if (mode == RN_FWD_FUSED) {
-            rn_epilogue ep;
-            ep.scale = stem->scale; ep.shift = stem->shift; ep.residual = NULL; ep.relu = 1;
-            STEP(op_conv(m, stem, m->x4, m->p1, B, H, W, &ep));
+        if (bf16) {
+            /* bf16 stem: [B,230,230,4] image with its own 3-pixel zero border, padding 0 */
+            const uint64_t border = stem->pad;
+            STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0,
+                            (double)B * (4.0 * 3 * 224 * 224 + es * 230 * 230 * 4)));
+            STEP(rn_nchw_to_nhwc_pad_dt(m->ctx, m->dtype, input_nchw, m->x4, B, 3, H, W, 4, border));
+            STEP(prof_end(m));
+            ho = rn_conv_output_size(H + 2 * border, stem->k, stem->stride, 0);
+            wo = rn_conv_output_size(W + 2 * border, stem->k, stem->stride, 0);
+            {
+                rn_epilogue ep;
+                ep.scale = stem->scale; ep.shift = stem->shift; ep.residual = NULL; ep.relu = 1;
+                STEP(op_conv(m, stem, m->x4, m->p1, B, H + 2 * border, W + 2 * border, &ep, 0));
+            }
         } else {
-            STEP(op_conv(m, stem, m->x4, m->p1, B, H, W, NULL));
-            STEP(op_bn(m, stem, m->p1, B, ho * wo));
-            STEP(op_relu(m, "conv1", m->p1, B * ho * wo * 64));
+            STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0, 4.0 * (double)(B * 224 * 224 * 7)));
+            STEP(rn_nchw_to_nhwc_pad(m->ctx, input_nchw, m->x4, B, 3, H, W, 4));
+            STEP(prof_end(m));
+            ho = rn_conv_output_size(H, stem->k, stem->stride, stem->pad);
+            wo = rn_conv_output_size(W, stem->k, stem->stride, stem->pad);
+            if (mode == RN_FWD_FUSED) {
+                rn_epilogue ep;
+                ep.scale = stem->scale; ep.shift = stem->shift; ep.residual = NULL; ep.relu = 1;
+                STEP(op_conv(m, stem, m->x4, m->p1, B, H, W, &ep, -1));
+            } else {
+                STEP(op_conv(m, stem, m->x4, m->p1, B, H, W, NULL, -1));
+                STEP(op_bn(m, stem, m->p1, B, ho * wo));
+                STEP(op_relu(m, "conv1", m->p1, B * ho * wo * 64));
+            }
         }
         /* maxpool 3x3 s2 p1 (main.cu:114,192) */
         ph = rn_conv_output_size(ho, 3, 2, 1);
         pw = rn_conv_output_size(wo, 3, 2, 1);
         STEP(prof_begin(m, "maxpool2d", "maxpool", 0.0,
-                        4.0 * (double)(B * 64 * (ho * wo + ph * pw))));
-        STEP(rn_maxpool2d_forward(m->ctx, m->p1, m->p0, 3, 2, 1, ph, pw, B, 64, ho, wo));
+                        es * (double)(B * 64 * (ho * wo + ph * pw))));
+        STEP(rn_maxpool2d_nhwc_forward_dt(m->ctx, m->dtype, m->p1, m->p0, 3, 2, 1, ph, pw, B, 64, ho,
+                                          wo));
         STEP(prof_end(m));
         H = ph;
         W = pw;
@@ -584,15 +651,24 @@ int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *lo
         }
         if (st != RN_OK) break;
         /* global 7x7 average (main.cu:120,213) then fc (main.cu:122,224) */
-        STEP(prof_begin(m, "avgpool2d", "avgpool", 0.0, 4.0 * (double)(B * 2048 * (H * W + 1))));
-        STEP(rn_avgpool2d_forward(m->ctx, x, m->pooled, 7, 1, 0, rn_conv_output_size(H, 7, 1, 0),
-                                  rn_conv_output_size(W, 7, 1, 0), B, 2048, H, W));
+        STEP(prof_begin(m, "avgpool2d", "avgpool", 0.0, es * (double)(B * 2048 * (H * W + 1))));
+        STEP(rn_avgpool2d_nhwc_forward_dt(m->ctx, m->dtype, x, m->pooled, 7, 1, 0,
+                                          rn_conv_output_size(H, 7, 1, 0),
+                                          rn_conv_output_size(W, 7, 1, 0), B, 2048, H, W));
         STEP(prof_end(m));
         STEP(prof_begin(m, "linear", "fc", 2.0 * (double)B * 2048.0 * RN_CLASSES,
-                        4.0 * ((double)B * 2048.0 + 2048.0 * RN_CLASSES + RN_CLASSES +
-                               (double)B * RN_CLASSES)));
-        STEP(rn_linear_forward(m->ctx, m->pooled, logits, m->params[m->fc_w].dev,
-                               m->params[m->fc_b].dev, B, 2048, RN_CLASSES));
+                        es * ((double)B * 2048.0 + 2048.0 * RN_CLASSES) +
+                            4.0 * (RN_CLASSES + (double)B * RN_CLASSES)));
+        if (bf16) {
+            rn_epilogue ep;
+            ep.scale = NULL; ep.shift = m->params[m->fc_b].dev; ep.residual = NULL; ep.relu = 0;
+            STEP(rn_conv2d_nhwc_forward_dt(m->ctx, m->dtype, RN_DTYPE_F32, m->pooled, logits,
+                                           m->fc_packed, 1, 1, 0, 1, 1, B, 2048, RN_CLASSES, 1, 1,
+                                           &ep));
+        } else {
+            STEP(rn_linear_forward(m->ctx, m->pooled, logits, m->params[m->fc_w].dev,
+                                   m->params[m->fc_b].dev, B, 2048, RN_CLASSES));
+        }
         STEP(prof_end(m));
 #undef STEP
     } while (0);
@@ -618,8 +694,8 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
     for (i = 0; st == RN_OK && i < m->n_calls; ++i) {
         const rn_conv_call *k = &m->calls[i];
         rn_conv *cv = &m->convs[k->conv];
-        const uint64_t ho = rn_conv_output_size(k->H, cv->k, cv->stride, cv->pad);
-        const uint64_t wo = rn_conv_output_size(k->W, cv->k, cv->stride, cv->pad);
+        const uint64_t ho = rn_conv_output_size(k->H, cv->k, cv->stride, k->pad);
+        const uint64_t wo = rn_conv_output_size(k->W, cv->k, cv->stride, k->pad);
         float best = 1e30f;
         int best_c = 0;
         for (c = 0; c <= ncand && st == RN_OK; ++c) { /* 0 = the per-launch choice itself */
@@ -629,9 +705,9 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
                 float t = 0.f;
                 st = rn_event_record(m->ctx, e0);
                 if (st == RN_OK)
-                    st = rn_conv2d_nhwc_forward(m->ctx, k->x, k->y, cv->packed, cv->k, cv->stride,
-                                                cv->pad, ho, wo, k->B, cv->cin, cv->cout, k->H, k->W,
-                                                k->has_ep ? &k->ep : NULL);
+                    st = rn_conv2d_nhwc_forward_dt(m->ctx, m->dtype, m->dtype, k->x, k->y, cv->packed,
+                                                   cv->k, cv->stride, k->pad, ho, wo, k->B, cv->cin,
+                                                   cv->cout, k->H, k->W, k->has_ep ? &k->ep : NULL);
                 if (st == RN_OK) st = rn_event_record(m->ctx, e1);
                 if (st == RN_OK) st = rn_event_elapsed_ms(e0, e1, &t);
                 if (r > 0 && t < ms) ms = t; /* first repetition warms the caches */

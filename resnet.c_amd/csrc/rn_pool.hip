@@ -111,6 +111,70 @@ __global__ __launch_bounds__(kBlock) void pool_scalar_kernel(const float *__rest
     }
 }
 
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+
+// bf16 NHWC, C % 8 == 0: 8 channels (16 bytes) per lane, fp32 max / sum
+template <bool kMax>
+__global__ __launch_bounds__(kBlock) void pool_nhwc_bf16_kernel(
+    const bf16_t *__restrict__ inp, bf16_t *__restrict__ out, int k, int stride, int pad, int Ho,
+    int Wo, int C8, int H, int W, uint64_t total8)
+{
+    const bf16x8 *in8 = reinterpret_cast<const bf16x8 *>(inp);
+    bf16x8 *out8 = reinterpret_cast<bf16x8 *>(out);
+    const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
+    const float kf = (float)k;
+    for (uint64_t i64 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i64 < total8; i64 += gstride) {
+        const uint32_t i = (uint32_t)i64;
+        const int c8 = (int)(i % (uint32_t)C8);
+        uint32_t pix = i / (uint32_t)C8;
+        const int ow = (int)(pix % (uint32_t)Wo);
+        pix /= (uint32_t)Wo;
+        const int oh = (int)(pix % (uint32_t)Ho);
+        const uint64_t b = pix / (uint32_t)Ho;
+        const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = kMax ? -INFINITY : 0.f;
+        for (int kh = 0; kh < k; ++kh) {
+            const int ih = ih0 + kh;
+            if (ih < 0 || ih >= H) continue;
+            for (int kw = 0; kw < k; ++kw) {
+                const int iw = iw0 + kw;
+                if (iw < 0 || iw >= W) continue;
+                const bf16x8 v = in8[((b * H + ih) * W + iw) * C8 + c8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = kMax ? fmaxf(acc[j], (float)v[j]) : acc[j] + (float)v[j];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(kMax ? acc[j] : acc[j] / kf / kf);
+        out8[i64] = o;
+    }
+}
+
+template <bool kMax>
+int pool_bf16_dispatch(rn_ctx *ctx, const void *inp, void *out, uint64_t k, uint64_t stride,
+                       uint64_t pad, uint64_t h_out, uint64_t w_out, uint64_t B, uint64_t C,
+                       uint64_t H, uint64_t W, const char *what)
+{
+    const uint64_t total = B * C * h_out * w_out;
+    if (total == 0) return RN_OK;
+    RN_REQUIRE(ctx, inp && out && inp != out, "null or aliased tensor");
+    RN_REQUIRE(ctx, k >= 1 && stride >= 1 && k < (1u << 15) && pad < (1u << 15) &&
+                        stride < (1u << 15) && H < (1u << 30) && W < (1u << 30),
+               "dimension out of range");
+    RN_REQUIRE(ctx, C % 8 == 0 && total / 8 < (1ull << 32), "bf16 pooling needs C % 8 == 0");
+    RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+               "bf16 tensors must be 16-byte aligned");
+    const uint64_t total8 = total / 8;
+    pool_nhwc_bf16_kernel<kMax><<<rn_stream_grid(total8, kBlock), kBlock, 0, ctx->stream>>>(
+        (const bf16_t *)inp, (bf16_t *)out, (int)k, (int)stride, (int)pad, (int)h_out, (int)w_out,
+        (int)(C / 8), (int)H, (int)W, total8);
+    return rn_after_launch(ctx, what);
+}
+
 template <bool kMax>
 int pool_dispatch(rn_ctx *ctx, const float *inp, float *out, uint64_t k, uint64_t stride,
                   uint64_t pad, uint64_t h_out, uint64_t w_out, uint64_t B, uint64_t C, uint64_t H,
@@ -149,6 +213,42 @@ uint64_t rn_conv_output_size(uint64_t x, uint64_t kernel_size, uint64_t stride, 
 {
     // cuda/ops.cuh:9-13: unsigned arithmetic, integer division
     return (2 * padding + x - kernel_size) / stride + 1;
+}
+
+int rn_maxpool2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, const void *inp, void *out,
+                                 uint64_t kernel_size, uint64_t stride, uint64_t padding,
+                                 uint64_t h_out, uint64_t w_out, uint64_t B, uint64_t channels,
+                                 uint64_t H, uint64_t W)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (dtype == RN_DTYPE_BF16)
+        return pool_bf16_dispatch<true>(ctx, inp, out, kernel_size, stride, padding, h_out, w_out, B,
+                                        channels, H, W, "rn_maxpool2d_nhwc_forward_dt");
+    RN_REQUIRE(ctx, dtype == RN_DTYPE_F32, "unknown dtype");
+    const int saved = ctx->layout;
+    ctx->layout = RN_LAYOUT_NHWC;
+    const int st = rn_maxpool2d_forward(ctx, (const float *)inp, (float *)out, kernel_size, stride,
+                                        padding, h_out, w_out, B, channels, H, W);
+    ctx->layout = saved;
+    return st;
+}
+
+int rn_avgpool2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, const void *inp, void *out,
+                                 uint64_t kernel_size, uint64_t stride, uint64_t padding,
+                                 uint64_t h_out, uint64_t w_out, uint64_t B, uint64_t channels,
+                                 uint64_t H, uint64_t W)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (dtype == RN_DTYPE_BF16)
+        return pool_bf16_dispatch<false>(ctx, inp, out, kernel_size, stride, padding, h_out, w_out,
+                                         B, channels, H, W, "rn_avgpool2d_nhwc_forward_dt");
+    RN_REQUIRE(ctx, dtype == RN_DTYPE_F32, "unknown dtype");
+    const int saved = ctx->layout;
+    ctx->layout = RN_LAYOUT_NHWC;
+    const int st = rn_avgpool2d_forward(ctx, (const float *)inp, (float *)out, kernel_size, stride,
+                                        padding, h_out, w_out, B, channels, H, W);
+    ctx->layout = saved;
+    return st;
 }
 
 int rn_maxpool2d_forward(rn_ctx *ctx, const float *inp, float *out, uint64_t kernel_size,

@@ -206,7 +206,8 @@ def argmax(logits: np.ndarray) -> np.ndarray:
 # ---------------------------------------------------------------------------
 class NativeModel:
     def __init__(self, arch: str = "resnet50", state: Optional[Dict[str, np.ndarray]] = None,
-                 weights_dir: Optional[str] = None, ctx: Optional[Context] = None):
+                 weights_dir: Optional[str] = None, ctx: Optional[Context] = None,
+                 dtype: str = "f32"):
         self.ctx = ctx or get_ctx()
         self.arch = arch
         lib = L.lib()
@@ -225,6 +226,9 @@ class NativeModel:
                 assert arr.size == numel, (key, arr.size, numel)
                 L.check(lib.rn_model_set_tensor(h, key.encode(), arr.ctypes.data, numel),
                         f"rn_model_set_tensor({key})", self.ctx.handle)
+        self.dtype = dtype
+        L.check(lib.rn_model_set_dtype(h, {"f32": L.RN_DTYPE_F32, "bf16": L.RN_DTYPE_BF16}[dtype]),
+                "rn_model_set_dtype", self.ctx.handle)
         L.check(lib.rn_model_finalize(h), "rn_model_finalize", self.ctx.handle)
 
     def tensor_keys(self) -> List[Tuple[str, int]]:

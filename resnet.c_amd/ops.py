@@ -147,3 +147,100 @@ def conv2d_nhwc_fused(x, w, stride=1, pad=0, scale=None, shift=None, residual=No
             "rn_conv2d_nhwc_forward", ctx.handle)
     ctx.sync()
     return _down(out, (B, Cout, ho, wo), "nhwc")
+
+
+# ---------------------------------------------------------------------------
+# bf16 storage (element-type tagged entry points)
+# ---------------------------------------------------------------------------
+def to_bf16_bits(a) -> np.ndarray:
+    """fp32 -> bf16 bit patterns (uint16), round to nearest even (what v_cvt_pk_bf16_f32 does)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    return ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)).astype(np.uint16)
+
+
+def from_bf16_bits(b) -> np.ndarray:
+    return (np.asarray(b, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def bf16_round(a) -> np.ndarray:
+    """fp32 values rounded to the nearest bf16, still stored as fp32."""
+    return from_bf16_bits(to_bf16_bits(a)).reshape(np.shape(a))
+
+
+def _up_raw(arr: np.ndarray):
+    from .tensor import _DeviceBuffer
+    ctx = get_ctx()
+    arr = np.ascontiguousarray(arr)
+    buf = _DeviceBuffer(ctx, max(arr.nbytes, 16))
+    L.check(L.lib().rn_memcpy_h2d(ctx.handle, buf.ptr, arr.ctypes.data, arr.nbytes), "h2d", ctx.handle)
+    return buf
+
+
+def _down_raw(buf, dtype, count: int) -> np.ndarray:
+    ctx = get_ctx()
+    out = np.empty(count, dtype=dtype)
+    L.check(L.lib().rn_memcpy_d2h(ctx.handle, out.ctypes.data, buf.ptr, out.nbytes), "d2h", ctx.handle)
+    return out
+
+
+def conv2d_nhwc_bf16(x, w, stride=1, pad=0, scale=None, shift=None, residual=None,
+                     relu_: bool = False, out_f32: bool = False) -> np.ndarray:
+    """bf16 activations/weights through rn_conv2d_pack_weight_dt + rn_conv2d_nhwc_forward_dt.
+    NCHW fp32 host arrays in (rounded to bf16 on upload), NCHW fp32 host array out.  The
+    small-Cin stem form gets a physically zero-padded image, as the model driver builds it."""
+    from .tensor import _DeviceBuffer
+    ctx, lib = get_ctx(), L.lib()
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    ho, wo = conv_output_size(H, k, stride, pad), conv_output_size(W, k, stride, pad)
+    c4 = Cin <= 4 and k <= 8
+    dx32 = _up(np.asarray(x, dtype=np.float32), "nchw")
+    if c4:
+        Hp, Wp = H + 2 * pad, W + 2 * pad
+        dx = _DeviceBuffer(ctx, B * Hp * Wp * 4 * 2)
+        L.check(lib.rn_nchw_to_nhwc_pad_dt(ctx.handle, L.RN_DTYPE_BF16, dx32.data(), dx.ptr, B, Cin,
+                                           H, W, 4, pad), "pad_dt", ctx.handle)
+        Hin, Win, pad_arg = Hp, Wp, 0
+    else:
+        dx = _up_raw(to_bf16_bits(np.asarray(x, dtype=np.float32).transpose(0, 2, 3, 1)))
+        Hin, Win, pad_arg = H, W, pad
+    dw = _up(w, "nchw")
+    pn = int(lib.rn_conv2d_packed_weight_numel_dt(L.RN_DTYPE_BF16, Cin, Cout, k))
+    packed = _DeviceBuffer(ctx, pn * 2)
+    L.check(lib.rn_conv2d_pack_weight_dt(ctx.handle, L.RN_DTYPE_BF16, dw.data(), packed.ptr, Cin,
+                                         Cout, k), "pack_dt", ctx.handle)
+    keep = [_up(v, "nchw") if v is not None else None for v in (scale, shift)]
+    dres = None
+    if residual is not None:
+        r = np.asarray(residual, dtype=np.float32).transpose(0, 2, 3, 1)
+        dres = _up_raw(r if out_f32 else to_bf16_bits(r))
+    ep = L.Epilogue(keep[0].data() if keep[0] else None, keep[1].data() if keep[1] else None,
+                    dres.ptr if dres else None, int(relu_))
+    n_out = B * Cout * ho * wo
+    out = _DeviceBuffer(ctx, n_out * (4 if out_f32 else 2))
+    L.check(lib.rn_conv2d_nhwc_forward_dt(ctx.handle, L.RN_DTYPE_BF16,
+                                          L.RN_DTYPE_F32 if out_f32 else L.RN_DTYPE_BF16, dx.ptr,
+                                          out.ptr, packed.ptr, k, stride, pad_arg, ho, wo, B, Cin,
+                                          Cout, Hin, Win, ctypes.byref(ep)),
+            "rn_conv2d_nhwc_forward_dt", ctx.handle)
+    ctx.sync()
+    if out_f32:
+        y = _down_raw(out, np.float32, n_out)
+    else:
+        y = from_bf16_bits(_down_raw(out, np.uint16, n_out))
+    return y.reshape(B, ho, wo, Cout).transpose(0, 3, 1, 2).copy()
+
+
+def pool_nhwc_bf16(x, k, stride=1, pad=0, is_max=True) -> np.ndarray:
+    from .tensor import _DeviceBuffer
+    ctx, lib = get_ctx(), L.lib()
+    B, C, H, W = x.shape
+    ho, wo = conv_output_size(H, k, stride, pad), conv_output_size(W, k, stride, pad)
+    dx = _up_raw(to_bf16_bits(np.asarray(x, dtype=np.float32).transpose(0, 2, 3, 1)))
+    out = _DeviceBuffer(ctx, B * C * ho * wo * 2)
+    fn = lib.rn_maxpool2d_nhwc_forward_dt if is_max else lib.rn_avgpool2d_nhwc_forward_dt
+    L.check(fn(ctx.handle, L.RN_DTYPE_BF16, dx.ptr, out.ptr, k, stride, pad, ho, wo, B, C, H, W),
+            "pool_dt", ctx.handle)
+    ctx.sync()
+    y = from_bf16_bits(_down_raw(out, np.uint16, B * C * ho * wo))
+    return y.reshape(B, ho, wo, C).transpose(0, 3, 1, 2).copy()

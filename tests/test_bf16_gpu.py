@@ -1,0 +1,94 @@
+"""bf16 storage / fp32 accumulate (BASELINE.json configs[3]).  The reference is fp32 only;
+the oracle for these kernels is the same CPU restatement run on bf16-rounded operands:
+products of bf16 values are exact in fp32, so the only differences are fp32 summation
+order and the final rounding of the output to bf16 (rel. 2^-9)."""
+import os
+
+import numpy as np
+import pytest
+
+import resnet_c_amd as R
+from oracle import oracle as O
+from resnet_c_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, seed):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+def test_bf16_rounding_helper_is_rne():
+    x = np.array([1.0, 1.00390625, 1.005859375, -2.5, 3.1415926, 0.0, 65504.0], dtype=np.float32)
+    b = ops.bf16_round(x)
+    assert b[0] == 1.0 and b[1] == 1.0  # 1 + 2^-8 is a tie -> even mantissa
+    assert b[2] == 1.0078125 and b[3] == -2.5
+    assert abs(b[4] - 3.1415926) <= 2 ** -7 and b[5] == 0.0
+
+
+CASES = [(2, 64, 64, 12, 12, 1, 1, 0), (1, 128, 128, 10, 10, 3, 1, 1), (2, 64, 96, 13, 11, 3, 2, 1),
+         (1, 256, 512, 8, 8, 1, 2, 0), (1, 3, 64, 32, 32, 7, 2, 3), (1, 3, 64, 224, 224, 7, 2, 3),
+         (3, 2048, 1000, 1, 1, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_bf16_conv_matches_oracle_on_rounded_operands(case):
+    B, Cin, Cout, H, W, k, s, p = case
+    x, w = rnd((B, Cin, H, W), 7 + sum(case)), rnd((Cout, Cin, k, k), 8 + sum(case)) / np.sqrt(Cin * k * k)
+    want = O.conv2d(ops.bf16_round(x), ops.bf16_round(w), s, p)
+    got32 = ops.conv2d_nhwc_bf16(x, w, s, p, out_f32=True)
+    scale = float(np.abs(want).max())
+    assert np.abs(got32 - want).max() <= 3e-7 * np.sqrt(Cin * k * k) * scale + 1e-6
+    got16 = ops.conv2d_nhwc_bf16(x, w, s, p)
+    assert np.array_equal(got16, ops.bf16_round(got32))  # bf16 output = RNE of the fp32 result
+
+
+def test_bf16_fused_epilogue():
+    B, Cin, Cout, H, W = 2, 64, 128, 9, 9
+    x, w = rnd((B, Cin, H, W), 1), rnd((Cout, Cin, 3, 3), 2) / 24
+    g = np.random.default_rng(3)
+    scale, shift = g.random(Cout, dtype=np.float32) + 0.5, g.standard_normal(Cout, dtype=np.float32)
+    res = rnd((B, Cout, H, W), 4)
+    y = O.conv2d(ops.bf16_round(x), ops.bf16_round(w), 1, 1)
+    want = np.maximum(y * scale[None, :, None, None] + shift[None, :, None, None] + ops.bf16_round(res), 0)
+    got = ops.conv2d_nhwc_bf16(x, w, 1, 1, scale, shift, res, True)
+    assert np.abs(got - want).max() <= 2 ** -8 * np.abs(want).max() + 1e-5
+
+
+def test_bf16_pools():
+    x = rnd((2, 64, 14, 14), 5)
+    xb = ops.bf16_round(x)
+    assert np.array_equal(ops.pool_nhwc_bf16(x, 3, 2, 1, True), O.maxpool2d(xb, 3, 2, 1))
+    x7 = rnd((2, 2048, 7, 7), 6)
+    want = ops.bf16_round(O.avgpool2d(ops.bf16_round(x7), 7))
+    assert np.array_equal(ops.pool_nhwc_bf16(x7, 7, 1, 0, False), want)
+
+
+def test_bf16_unsupported_shapes_are_reported_not_guessed():
+    from resnet_c_amd import _lib as L
+    with pytest.raises(R.RnError) as e:
+        ops.conv2d_nhwc_bf16(rnd((1, 32, 4, 4), 1), rnd((8, 32, 1, 1), 2))
+    assert e.value.status == L.RN_ERR_UNSUPPORTED
+
+
+def test_bf16_model_agrees_with_fp32_model(state50, finch, golden_dir):
+    m32 = R.NativeModel("resnet50", state=state50)
+    m16 = R.NativeModel("resnet50", state=state50, dtype="bf16")
+    try:
+        x = R.weights.generate_input(6, seed=41)
+        x[2] = finch[0]
+        a, b = m32.forward(x, fused=True), m16.forward(x, fused=True)
+        golden = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
+        # bf16 has 8 significant bits; through 53 layers the logits (|.| <= 3.6) move by ~1e-2
+        assert np.abs(a - b).max() <= 0.12
+        assert np.abs(b[2:3] - golden).max() <= 0.12
+        assert np.array_equal(a.argmax(1), b.argmax(1))  # top-1 agreement (config 4's parity bar)
+        # batch invariance and determinism hold in bf16 too
+        assert np.array_equal(b[2:3], m16.forward(finch, fused=True))
+        assert np.array_equal(b, m16.forward(x, fused=True))
+        with pytest.raises(R.RnError):
+            m16.forward(x, fused=False)  # bf16 storage exists only with fused epilogues
+        assert m16.activation_bytes() * 2 == m32.activation_bytes()
+    finally:
+        m32.close()
+        m16.close()

@@ -20,9 +20,10 @@ def main():
     ap.add_argument("--mode", default="fused")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--tune", action="store_true")
+    ap.add_argument("--dtype", default="f32")
     a = ap.parse_args()
     state = R.weights.generate_state(a.arch, 0)
-    m = R.NativeModel(a.arch, state=state)
+    m = R.NativeModel(a.arch, state=state, dtype=a.dtype)
     x = R.FloatTensor.from_numpy(R.weights.generate_input(a.batch, 0), R.Device.GPU)
     out = R.FloatTensor((a.batch, 1000), R.Device.GPU)
     fused = a.mode == "fused"
