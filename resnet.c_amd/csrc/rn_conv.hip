@@ -109,10 +109,14 @@ struct OutVec;
 template <>
 struct OutVec<float> {
     static constexpr int EPT = 4;
-    static __device__ __forceinline__ void load(const void *base, size_t idx, float (&v)[4])
+    static __device__ __forceinline__ u32x4 load_raw(const void *base, size_t idx)
     {
-        const float4 x = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + idx);
-        v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w;
+        return *reinterpret_cast<const u32x4 *>(static_cast<const float *>(base) + idx);
+    }
+    static __device__ __forceinline__ void unpack(const u32x4 &x, float (&v)[4])
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(x[j]);
     }
     static __device__ __forceinline__ void store(void *base, size_t idx, const float (&v)[4])
     {
@@ -131,9 +135,13 @@ struct OutVec<float> {
 template <>
 struct OutVec<bf16_t> {
     static constexpr int EPT = 8;
-    static __device__ __forceinline__ void load(const void *base, size_t idx, float (&v)[8])
+    static __device__ __forceinline__ u32x4 load_raw(const void *base, size_t idx)
     {
-        const bf16x8 x = *reinterpret_cast<const bf16x8 *>(static_cast<const bf16_t *>(base) + idx);
+        return *reinterpret_cast<const u32x4 *>(static_cast<const bf16_t *>(base) + idx);
+    }
+    static __device__ __forceinline__ void unpack(const u32x4 &r, float (&v)[8])
+    {
+        const bf16x8 x = __builtin_bit_cast(bf16x8, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
     }
@@ -313,7 +321,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         }
     };
 
+    // epilogue geometry (16 bytes of one output row per thread and pass), known up front so
+    // that the residual tile can be fetched while the K loop runs
+    constexpr int EPT = OutVec<TO>::EPT;  // output elements per thread and pass (16 bytes)
+    constexpr int CV = BN / EPT;          // threads per tile row
+    constexpr int RPP = 256 / CV;         // tile rows per pass of the block
+    constexpr int PASSES = BM / RPP;
+    const int cv = t % CV, rr = t / CV;
+    const int n = n0 + cv * EPT;
+    const bool vec = (p.Cout % EPT) == 0;  // then n + EPT <= Cout and rows are 16-B aligned
+    const bool res_pre = p.residual != nullptr && vec && n < p.Cout;
+    u32x4 resv[PASSES];
+
     load_tile(0);
+    if (res_pre) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int m = m0 + rr + ps * RPP;
+            resv[ps] = m < p.M ? OutVec<TO>::load_raw(p.residual, (size_t)m * p.Cout + n)
+                               : u32x4{0u, 0u, 0u, 0u};
+        }
+    }
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < p.nk; ++kt) {
@@ -339,14 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         }
     __syncthreads();
 
-    constexpr int EPT = OutVec<TO>::EPT;  // output elements per thread and pass (16 bytes)
-    constexpr int CV = BN / EPT;          // threads per tile row
-    constexpr int RPP = 256 / CV;         // tile rows per pass of the block
-    constexpr int PASSES = BM / RPP;
-    const int cv = t % CV, rr = t / CV;
-    const int n = n0 + cv * EPT;
     if (n >= p.Cout) return;
-    const bool vec = (p.Cout % EPT) == 0;  // then n + EPT <= Cout and rows are 16-B aligned
     float sc[EPT], sh[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
@@ -359,25 +380,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     }
     const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
     if (vec) {
-        float res[PASSES][EPT];
-        if (p.residual) {
-#pragma unroll
-            for (int ps = 0; ps < PASSES; ++ps) {
-                const int m = m0 + rr + ps * RPP;
-                if (m < p.M) {
-                    OutVec<TO>::load(p.residual, (size_t)m * p.Cout + n, res[ps]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < EPT; ++j) res[ps][j] = 0.f;
-                }
-            }
-        }
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = rr + ps * RPP;
             const int m = m0 + row;
             if (m >= p.M) continue;
-            float v[EPT];
+            float v[EPT], res[EPT];
+            if (p.residual) OutVec<TO>::unpack(resv[ps], res);
 #pragma unroll
             for (int j4 = 0; j4 < EPT / 4; ++j4) {
                 const float4 x = *reinterpret_cast<const float4 *>(Cs + row * BN + cv * EPT + 4 * j4);
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
                     } else if (has_shift) {
                         y += sh[j];
                     }
-                    y += res[ps][j];
+                    y += res[j];
                     v[j] = p.relu ? fmaxf(y, 0.f) : y;
                 } else {
                     // no "+ 0.f": keeps -0.0 results of the plain convolution bit-exact
