@@ -7,9 +7,13 @@
 //
 // Batch-norm keeps the reference's arithmetic (cuda/ops.cu:149-150): because
 // `1e-5` is a double literal the whole expression is evaluated in double and
-// rounded to fp32 once at the store.  sqrt(var[c] + 1e-5) depends on the
-// channel only, so a tiny prologue kernel evaluates it once per channel (same
-// double value the reference recomputes per element) into context scratch.
+// rounded to fp32 once at the store.  d = sqrt(var[c] + 1e-5) depends on the
+// channel only, so a tiny prologue kernel evaluates d and 1/d once per channel
+// (same double values the reference recomputes per element) into context
+// scratch.  The per-element quotient (x - mean) / d is then formed as
+// q0 = a * (1/d); r = fma(-q0, d, a); q = fma(r, 1/d, q0), which is the correctly
+// rounded double quotient (Markstein) at 3 FMAs -- a full IEEE v_div sequence per
+// element made this kernel compute-bound at 2.1 TB/s instead of HBM-bound.
 #include "rn_internal.h"
 
 namespace {
@@ -69,62 +73,106 @@ __global__ __launch_bounds__(kBlock) void add_scalar_kernel(const float *a, cons
         out[i] = a[i] + b[i];
 }
 
-// per channel: {mean, sqrt(var + 1e-5), weight, bias} as doubles
+constexpr int kBnStride = 8;  // doubles per channel: {mean, d, 1/d, weight, bias, pad x3}
+
 __global__ void bn_prep_kernel(const float *weight, const float *bias, const float *mean,
                                const float *var, double *params, uint64_t C)
 {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    params[4 * c + 0] = (double)mean[c];
-    params[4 * c + 1] = sqrt((double)var[c] + 1e-5);
-    params[4 * c + 2] = (double)weight[c];
-    params[4 * c + 3] = (double)bias[c];
+    const double d = sqrt((double)var[c] + 1e-5);
+    double *p = params + kBnStride * c;
+    p[0] = (double)mean[c];
+    p[1] = d;
+    p[2] = 1.0 / d;
+    p[3] = (double)weight[c];
+    p[4] = (double)bias[c];
 }
 
 __device__ __forceinline__ float bn_apply(float x, const double *p)
 {
-    return (float)(((double)x - p[0]) / p[1] * p[2] + p[3]);
+    const double a = (double)x - p[0];
+    const double q0 = a * p[2];
+    const double r = fma(-q0, p[1], a);
+    const double q = fma(r, p[2], q0);  // == a / d, correctly rounded
+    return (float)(q * p[3] + p[4]);
 }
 
-// NCHW, N % 4 == 0: one float4 never straddles a (b, c) plane.
-__global__ __launch_bounds__(kBlock) void bn_nchw_vec_kernel(const float *inp,
-                                                             float *out,
+struct BnParams {
+    double m, d, rinv, g, beta;
+};
+
+__device__ __forceinline__ BnParams bn_load(const double *p)
+{
+    BnParams q;
+    q.m = p[0], q.d = p[1], q.rinv = p[2], q.g = p[3], q.beta = p[4];
+    return q;
+}
+
+__device__ __forceinline__ float bn_apply_reg(float x, const BnParams &p)
+{
+    const double a = (double)x - p.m;
+    const double q0 = a * p.rinv;
+    const double r = fma(-q0, p.d, a);
+    const double q = fma(r, p.rinv, q0);
+    return (float)(q * p.g + p.beta);
+}
+
+// NCHW, N % 4 == 0: one wave walks one (b, c) plane at a time, so the channel's five
+// doubles are wave-uniform (scalar registers) and the lanes stream the plane as float4.
+__global__ __launch_bounds__(kBlock) void bn_nchw_vec_kernel(const float *inp, float *out,
                                                              const double *__restrict__ params,
-                                                             uint64_t total4, uint32_t n4,
+                                                             uint32_t planes, uint32_t n4,
                                                              uint32_t C)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    const float4 *in4 = reinterpret_cast<const float4 *>(inp);
-    float4 *out4 = reinterpret_cast<float4 *>(out);
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += stride) {
-        const uint32_t plane = (uint32_t)(i / n4);
-        const double *p = params + 4 * (uint64_t)(plane % C);
-        float4 v = in4[i];
-        v.x = bn_apply(v.x, p);
-        v.y = bn_apply(v.y, p);
-        v.z = bn_apply(v.z, p);
-        v.w = bn_apply(v.w, p);
-        out4[i] = v;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    for (uint32_t plane = wave; plane < planes; plane += nwaves) {
+        const BnParams p = bn_load(params + kBnStride * (uint64_t)(plane % C));
+        const float4 *in4 = reinterpret_cast<const float4 *>(inp) + (uint64_t)plane * n4;
+        float4 *out4 = reinterpret_cast<float4 *>(out) + (uint64_t)plane * n4;
+        for (uint32_t i = lane; i < n4; i += 64) {
+            float4 v = in4[i];
+            v.x = bn_apply_reg(v.x, p);
+            v.y = bn_apply_reg(v.y, p);
+            v.z = bn_apply_reg(v.z, p);
+            v.w = bn_apply_reg(v.w, p);
+            out4[i] = v;
+        }
     }
 }
 
-// NHWC, C % 4 == 0: a float4 covers channels c4*4 .. c4*4+3 of one pixel.
-__global__ __launch_bounds__(kBlock) void bn_nhwc_vec_kernel(const float *inp,
-                                                             float *out,
+// NHWC, C % 4 == 0: a float4 covers channels c4*4 .. c4*4+3 of one pixel.  When the grid
+// stride is a multiple of C/4 every thread keeps the same four channels for its whole
+// walk, so their parameters are loaded once into registers (kFixed); reloading 20
+// doubles per float4 through the vector cache made the kernel load-issue bound.
+template <bool kFixed>
+__global__ __launch_bounds__(kBlock) void bn_nhwc_vec_kernel(const float *inp, float *out,
                                                              const double *__restrict__ params,
                                                              uint64_t total4, uint32_t c4n)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const float4 *in4 = reinterpret_cast<const float4 *>(inp);
     float4 *out4 = reinterpret_cast<float4 *>(out);
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += stride) {
-        const uint32_t c4 = (uint32_t)(i % c4n);
-        const double *p = params + 16 * (uint64_t)c4;
+    const uint64_t first = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    BnParams p0, p1, p2, p3;
+    if (kFixed) {
+        const double *p = params + 4 * kBnStride * (first % c4n);
+        p0 = bn_load(p), p1 = bn_load(p + kBnStride), p2 = bn_load(p + 2 * kBnStride),
+        p3 = bn_load(p + 3 * kBnStride);
+    }
+    for (uint64_t i = first; i < total4; i += stride) {
+        if (!kFixed) {
+            const double *p = params + 4 * kBnStride * (uint64_t)(uint32_t)(i % c4n);
+            p0 = bn_load(p), p1 = bn_load(p + kBnStride), p2 = bn_load(p + 2 * kBnStride),
+            p3 = bn_load(p + 3 * kBnStride);
+        }
         float4 v = in4[i];
-        v.x = bn_apply(v.x, p);
-        v.y = bn_apply(v.y, p + 4);
-        v.z = bn_apply(v.z, p + 8);
-        v.w = bn_apply(v.w, p + 12);
+        v.x = bn_apply_reg(v.x, p0);
+        v.y = bn_apply_reg(v.y, p1);
+        v.z = bn_apply_reg(v.z, p2);
+        v.w = bn_apply_reg(v.w, p3);
         out4[i] = v;
     }
 }
@@ -137,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void bn_scalar_kernel(const float *inp, flo
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
         const uint64_t c = nhwc ? (i % C) : ((i / N) % C);
-        out[i] = bn_apply(inp[i], params + 4 * c);
+        out[i] = bn_apply(inp[i], params + kBnStride * c);
     }
 }
 
@@ -228,20 +276,33 @@ int rn_batchnorm2d_forward(rn_ctx *ctx, const float *inp, float *out, const floa
     RN_REQUIRE(ctx, inp && out && weight && bias && mean && var, "null tensor");
     RN_REQUIRE(ctx, C < (1ull << 31) && N < (1ull << 32), "dimension too large");
     void *scratch = nullptr;
-    RN_TRY(rn_scratch(ctx, 0, C * 4 * sizeof(double), &scratch));
+    RN_TRY(rn_scratch(ctx, 0, C * kBnStride * sizeof(double), &scratch));
     double *params = static_cast<double *>(scratch);
     bn_prep_kernel<<<(unsigned)rn_ceil_div(C, 256), 256, 0, ctx->stream>>>(weight, bias, mean, var,
                                                                          params, C);
     const bool al = aligned16(inp) && aligned16(out);
     if (ctx->layout == RN_LAYOUT_NHWC && al && C % 4 == 0) {
         const uint64_t total4 = total / 4;
-        bn_nhwc_vec_kernel<<<rn_stream_grid(total4, kBlock), kBlock, 0, ctx->stream>>>(
-            inp, out, params, total4, (uint32_t)(C / 4));
-    } else if (ctx->layout == RN_LAYOUT_NCHW && al && N % 4 == 0 &&
-               total / 4 / (N / 4) < (1ull << 32)) {
-        const uint64_t total4 = total / 4;
-        bn_nchw_vec_kernel<<<rn_stream_grid(total4, kBlock), kBlock, 0, ctx->stream>>>(
-            inp, out, params, total4, (uint32_t)(N / 4), (uint32_t)C);
+        const uint32_t c4n = (uint32_t)(C / 4);
+        unsigned grid = rn_stream_grid(total4, kBlock);
+        // make the grid stride a multiple of C/4 when a nearby grid size allows it
+        bool fixed = false;
+        for (unsigned g = grid; g >= 1 && g + 64 > grid; --g) {
+            if (((uint64_t)g * kBlock) % c4n == 0) {
+                grid = g;
+                fixed = true;
+                break;
+            }
+        }
+        if (fixed)
+            bn_nhwc_vec_kernel<true><<<grid, kBlock, 0, ctx->stream>>>(inp, out, params, total4, c4n);
+        else
+            bn_nhwc_vec_kernel<false><<<grid, kBlock, 0, ctx->stream>>>(inp, out, params, total4, c4n);
+    } else if (ctx->layout == RN_LAYOUT_NCHW && al && N % 4 == 0 && B * C < (1ull << 32)) {
+        const uint64_t planes = B * C;
+        const unsigned grid = rn_stream_grid(planes * 64, kBlock);
+        bn_nchw_vec_kernel<<<grid, kBlock, 0, ctx->stream>>>(inp, out, params, (uint32_t)planes,
+                                                             (uint32_t)(N / 4), (uint32_t)C);
     } else {
         bn_scalar_kernel<<<rn_stream_grid(total, kBlock), kBlock, 0, ctx->stream>>>(
             inp, out, params, total, N, C, ctx->layout == RN_LAYOUT_NHWC);
