@@ -70,6 +70,7 @@ struct GemmParams {
     int Ktot;       // packed weight row length in elements
     int nk;         // K tiles
     int tiles_n;
+    unsigned total_tiles;  // the grid may be smaller: blocks then walk tiles grid-stride
     int HoWo;
     unsigned mul_hw, shr_hw, mul_w, shr_w;  // n / d == umulhi(n, mul) >> shr for n < 2^31
     int in_bytes, w_bytes;
@@ -174,13 +175,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     constexpr int STAGE = (BM + BN) * ROW_FLOATS;
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
-    // XCD-aware tile order (bijective for any grid size)
-    const unsigned nwg = gridDim.x, bid = blockIdx.x;
-    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tile_n = (int)(logical % (unsigned)p.tiles_n);
-    const int tile_m = (int)(logical / (unsigned)p.tiles_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // XCD-aware tile order (bijective for any tile count): virtual block v of total_tiles
+    // gets the v-th tile of its XCD's contiguous range, N tiles of one M panel adjacent.
+    // A block walks v = blockIdx.x, + gridDim.x, ... (persistent when the grid is smaller
+    // than the tile count: the next tile's operands are fetched during this tile's epilogue).
+    const unsigned total_tiles = p.total_tiles;
+    auto tile_origin = [&](unsigned v, int &m0_, int &n0_) {
+        const unsigned q = total_tiles >> 3, r = total_tiles & 7, xcd = v & 7;
+        const unsigned logical =
+            (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        n0_ = (int)(logical % (unsigned)p.tiles_n) * BN;
+        m0_ = (int)(logical / (unsigned)p.tiles_n) * BM;
+    };
+    unsigned vtile = blockIdx.x;
+    int m0, n0;
+    tile_origin(vtile, m0, n0);
 
     const int t = threadIdx.x;
     const int c = t & 7;    // 16-byte chunk of the 128-byte row this thread stages
@@ -196,38 +205,40 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     constexpr int kOob = (int)0x80000000;  // >= num_records for every tensor we accept
 
     // per staged A row: byte offset of tap (0,0) chunk c, and which taps are in bounds:
-    // bit kh of the low half = row ih0+kh inside [0,H), bit kw of the high half = column
-    int a_off[AP], a_mask[AP];
+    // bit kh of the low half = row ih0+kh inside [0,H), bit kw of the high half = column;
+    // per staged B row: constant per-thread offset (the K tile goes into the scalar offset)
+    int a_off[AP], a_mask[AP], b_off[BP];
+    auto setup_rows = [&](int m0_, int n0_) {
 #pragma unroll
-    for (int j = 0; j < AP; ++j) {
-        const int m = m0 + r0 + 32 * j;
-        if (m < p.M) {
-            const int b = p.HoWo == 1 ? m : (int)(__umulhi((unsigned)m, p.mul_hw) >> p.shr_hw);
-            const int rem = m - b * p.HoWo;
-            const int oh = p.Wo == 1 ? rem : (int)(__umulhi((unsigned)rem, p.mul_w) >> p.shr_w);
-            const int ow = rem - oh * p.Wo;
-            const int ih0 = oh * p.stride - p.pad;
-            const int iw0 = ow * p.stride - p.pad;
-            const int iwc = iw0 + c * p.chunk_dw;
-            a_off[j] = (((b * p.H + ih0) * p.W + iw0) * p.Cs + c * CH) * ES;
-            const int rlo = max(0, -ih0), rhi = min(p.KH, p.H - ih0);
-            const int clo = max(0, -iwc), chi = min(p.KW, p.W - iwc);
-            const int rm = rhi > rlo ? ((1 << rhi) - 1) & ~((1 << rlo) - 1) : 0;
-            int cm = chi > clo ? ((1 << chi) - 1) & ~((1 << clo) - 1) : 0;
-            if (p.chunk_dw && c >= p.c4_chunks) cm = 0;  // chunk holds only zero-weight slots
-            a_mask[j] = rm | (cm << 16);
-        } else {
-            a_off[j] = 0;
-            a_mask[j] = 0;
+        for (int j = 0; j < AP; ++j) {
+            const int m = m0_ + r0 + 32 * j;
+            if (m < p.M) {
+                const int b = p.HoWo == 1 ? m : (int)(__umulhi((unsigned)m, p.mul_hw) >> p.shr_hw);
+                const int rem = m - b * p.HoWo;
+                const int oh = p.Wo == 1 ? rem : (int)(__umulhi((unsigned)rem, p.mul_w) >> p.shr_w);
+                const int ow = rem - oh * p.Wo;
+                const int ih0 = oh * p.stride - p.pad;
+                const int iw0 = ow * p.stride - p.pad;
+                const int iwc = iw0 + c * p.chunk_dw;
+                a_off[j] = (((b * p.H + ih0) * p.W + iw0) * p.Cs + c * CH) * ES;
+                const int rlo = max(0, -ih0), rhi = min(p.KH, p.H - ih0);
+                const int clo = max(0, -iwc), chi = min(p.KW, p.W - iwc);
+                const int rm = rhi > rlo ? ((1 << rhi) - 1) & ~((1 << rlo) - 1) : 0;
+                int cm = chi > clo ? ((1 << chi) - 1) & ~((1 << clo) - 1) : 0;
+                if (p.chunk_dw && c >= p.c4_chunks) cm = 0;  // chunk holds only zero-weight slots
+                a_mask[j] = rm | (cm << 16);
+            } else {
+                a_off[j] = 0;
+                a_mask[j] = 0;
+            }
         }
-    }
-    // per staged B row: constant per-thread offset, the K tile goes into the scalar offset
-    int b_off[BP];
 #pragma unroll
-    for (int j = 0; j < BP; ++j) {
-        const int n = n0 + r0 + 32 * j;
-        b_off[j] = n < p.Cout ? (n * p.Ktot + c * CH) * ES : kOob;
-    }
+        for (int j = 0; j < BP; ++j) {
+            const int n = n0_ + r0 + 32 * j;
+            b_off[j] = n < p.Cout ? (n * p.Ktot + c * CH) * ES : kOob;
+        }
+    };
+    setup_rows(m0, n0);
 
     u32x4 ra[AP], rb[BP];
     int kh = 0, kw = 0, cs = 0;  // K-loop position of the tile being LOADED (wave-uniform)
@@ -280,12 +291,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     const int sw = (li >> 1) & 7;  // swizzle term of this lane's fragment rows
 
     f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
 
     auto compute_tile = [&](int buf) {
         const float *As = lds + buf * STAGE + (wr * (BM / 2) + li) * ROW_FLOATS;
@@ -321,42 +326,60 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         }
     };
 
-    // epilogue geometry (16 bytes of one output row per thread and pass), known up front so
-    // that the residual tile can be fetched while the K loop runs
+    // epilogue geometry: 16 bytes of one output row per thread and pass
     constexpr int EPT = OutVec<TO>::EPT;  // output elements per thread and pass (16 bytes)
     constexpr int CV = BN / EPT;          // threads per tile row
     constexpr int RPP = 256 / CV;         // tile rows per pass of the block
     constexpr int PASSES = BM / RPP;
     const int cv = t % CV, rr = t / CV;
-    const int n = n0 + cv * EPT;
     const bool vec = (p.Cout % EPT) == 0;  // then n + EPT <= Cout and rows are 16-B aligned
-    const bool res_pre = p.residual != nullptr && vec && n < p.Cout;
     u32x4 resv[PASSES];
 
     load_tile(0);
-    if (res_pre) {
+    for (;;) {
+        // the residual tile is fetched now, so that it travels while the K loop runs
+        const int n = n0 + cv * EPT;
+        const bool res_pre = p.residual != nullptr && vec && n < p.Cout;
+        if (res_pre) {
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int m = m0 + rr + ps * RPP;
-            resv[ps] = m < p.M ? OutVec<TO>::load_raw(p.residual, (size_t)m * p.Cout + n)
-                               : u32x4{0u, 0u, 0u, 0u};
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int m = m0 + rr + ps * RPP;
+                resv[ps] = m < p.M ? OutVec<TO>::load_raw(p.residual, (size_t)m * p.Cout + n)
+                                   : u32x4{0u, 0u, 0u, 0u};
+            }
         }
-    }
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < p.nk; ++kt) {
-        const bool more = kt + 1 < p.nk;
-        if (more) load_tile(kt + 1);
-        compute_tile(kt & 1);
-        if (more) store_tile((kt + 1) & 1);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+        store_tile(0);
         __syncthreads();
-    }
+        for (int kt = 0; kt < p.nk; ++kt) {
+            const bool more = kt + 1 < p.nk;
+            if (more) load_tile(kt + 1);
+            compute_tile(kt & 1);
+            if (more) store_tile((kt + 1) & 1);
+            __syncthreads();
+        }
 
-    // epilogue.  The accumulators go through LDS (free after the K loop) so that global
-    // traffic is row-contiguous 16-byte accesses: C/D map of the 32x32 MFMA is col = lane&31,
-    // row = (e&3) + 8*(e>>2) + 4*(lane>>5); a ds_write_b32 of one register puts 32
-    // consecutive columns of two rows, conflict-free.
-    float *Cs = lds;  // [BM][BN] fp32
+        // next tile of this block: its first K tile starts travelling before the epilogue
+        const unsigned vnext = vtile + gridDim.x;
+        const bool has_next = vnext < total_tiles;
+        int m0n = 0, n0n = 0;
+        if (has_next) {
+            tile_origin(vnext, m0n, n0n);
+            setup_rows(m0n, n0n);
+            kh = kw = cs = 0;
+            load_tile(0);
+        }
+
+        // epilogue.  The accumulators go through LDS (free after the K loop) so that global
+        // traffic is row-contiguous 16-byte accesses: C/D map of the 32x32 MFMA is
+        // col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); a ds_write_b32 of one register
+        // puts 32 consecutive columns of two rows, conflict-free.
+        float *Cs = lds;  // [BM][BN] fp32
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -367,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         }
     __syncthreads();
 
-    if (n >= p.Cout) return;
+    if (n < p.Cout) {
     float sc[EPT], sh[EPT];
 #pragma unroll
     for (int j = 0; j < EPT; ++j) {
@@ -433,6 +456,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
                 OutVec<TO>::store1(p.out, o, y);
             }
         }
+    }
+    }  // n < Cout
+        if (!has_next) break;
+        __syncthreads();  // the C staging area becomes operand stage 0 again
+        vtile = vnext;
+        m0 = m0n;
+        n0 = n0n;
     }
 }
 
@@ -524,18 +554,44 @@ void fast_div(unsigned d, unsigned *mul, unsigned *shr)
     *shr = p - 32;
 }
 
-template <typename T, typename TO>
-void launch_tiles(rn_ctx *ctx, const GemmParams &p, int BMsel, int BNsel, unsigned grid)
+// Blocks of one instantiation that fit a CU at once (registers and LDS), asked once.
+template <typename T, typename TO, int BM, int BN>
+int resident_blocks_per_cu()
 {
-    dim3 g(grid), blk(256);
+    static int cached = 0;
+    if (cached == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_kernel<T, TO, BM, BN>, 256,
+                                                         0) != hipSuccess ||
+            nb < 1)
+            nb = 1;
+        cached = nb;
+    }
+    return cached;
+}
+
+template <typename T, typename TO, int BM, int BN>
+void launch_one(rn_ctx *ctx, GemmParams &p, bool persistent)
+{
+    unsigned grid = p.total_tiles;
+    if (persistent) {
+        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN>();
+        if (grid > slots) grid = slots;
+    }
+    conv_gemm_kernel<T, TO, BM, BN><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
+}
+
+template <typename T, typename TO>
+void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent)
+{
     if (BMsel == 128 && BNsel == 128)
-        conv_gemm_kernel<T, TO, 128, 128><<<g, blk, 0, ctx->stream>>>(p);
+        launch_one<T, TO, 128, 128>(ctx, p, persistent);
     else if (BMsel == 128 && BNsel == 64)
-        conv_gemm_kernel<T, TO, 128, 64><<<g, blk, 0, ctx->stream>>>(p);
+        launch_one<T, TO, 128, 64>(ctx, p, persistent);
     else if (BMsel == 64 && BNsel == 128)
-        conv_gemm_kernel<T, TO, 64, 128><<<g, blk, 0, ctx->stream>>>(p);
+        launch_one<T, TO, 64, 128>(ctx, p, persistent);
     else
-        conv_gemm_kernel<T, TO, 64, 64><<<g, blk, 0, ctx->stream>>>(p);
+        launch_one<T, TO, 64, 64>(ctx, p, persistent);
 }
 
 // GEMM launch on NHWC data with packed weights.  Caller has checked eligibility.
@@ -585,9 +641,12 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     static const double cand_eff[4] = {1.00, 0.94, 0.94, 0.86};
     int BMsel = 128, BNsel = 128;
-    if (ctx->conv_tile >= 1 && ctx->conv_tile <= 4) {
-        BMsel = cand[ctx->conv_tile - 1][0];
-        BNsel = cand[ctx->conv_tile - 1][1];
+    bool persistent;
+    if (ctx->conv_tile >= 1 && ctx->conv_tile <= 8) {
+        // candidates 1-4: one block per tile; 5-8: the same tiles walked by a resident grid
+        BMsel = cand[(ctx->conv_tile - 1) & 3][0];
+        BNsel = cand[(ctx->conv_tile - 1) & 3][1];
+        persistent = ctx->conv_tile > 4;
     } else {
         double best = 1e300;
         for (int ci = 0; ci < 4; ++ci) {
@@ -601,18 +660,20 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
                 BNsel = cand[ci][1];
             }
         }
+        persistent = true;
     }
     const uint64_t tiles_n = rn_ceil_div(Cout, BNsel);
     const uint64_t tiles_m = rn_ceil_div((uint64_t)p.M, BMsel);
     p.tiles_n = (int)tiles_n;
-    const uint64_t grid = tiles_m * tiles_n;
-    RN_REQUIRE(ctx, fits_i32(grid), "too many tiles");
+    const uint64_t total = tiles_m * tiles_n;
+    RN_REQUIRE(ctx, fits_i32(total), "too many tiles");
+    p.total_tiles = (unsigned)total;
     if (dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)
-        launch_tiles<float, float>(ctx, p, BMsel, BNsel, (unsigned)grid);
+        launch_tiles<float, float>(ctx, p, BMsel, BNsel, persistent);
     else if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_BF16)
-        launch_tiles<bf16_t, bf16_t>(ctx, p, BMsel, BNsel, (unsigned)grid);
+        launch_tiles<bf16_t, bf16_t>(ctx, p, BMsel, BNsel, persistent);
     else if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_F32)
-        launch_tiles<bf16_t, float>(ctx, p, BMsel, BNsel, (unsigned)grid);
+        launch_tiles<bf16_t, float>(ctx, p, BMsel, BNsel, persistent);
     else
         return rn_set_error(ctx, RN_ERR_UNSUPPORTED, "%s: dtype combination %d -> %d", what, dt_in,
                             dt_out);
