@@ -145,7 +145,7 @@ int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate)
     return RN_OK;
 }
 
-int rn_conv_tile_candidates(void) { return 4; }
+int rn_conv_tile_candidates(void) { return 8; }
 
 void *rn_ctx_stream(rn_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int rn_ctx_device(const rn_ctx *ctx) { return ctx ? ctx->device : -1; }
