@@ -97,7 +97,7 @@ def max_over_ranks(value: float, world: int, device=None) -> float:
     return float(t.item())
 
 
-def cpu_baseline(arch: str, state, seconds_budget: float = 20.0):
+def cpu_baseline(arch: str, state, seconds_budget: float = 15.0):
     """Reference-equivalent PyTorch forward on the host CPU, bounded sample."""
     import numpy as np
     import torch
@@ -106,14 +106,17 @@ def cpu_baseline(arch: str, state, seconds_budget: float = 20.0):
     from oracle import torch_port as TP
 
     t = TP.to_torch(state)
-    threads = torch.get_num_threads()
-    B = 16
+    # a 1-GPU box gives this process about 16 host cores; oversubscribing the 256-thread host
+    # makes oneDNN slower, not faster (measured: 30 img/s at 16 threads, 10 img/s at 128)
+    threads = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    B = 32
     x = torch.from_numpy(R.weights.generate_input(B, seed=123))
     TP.resnet_forward(t, x[:2], arch)  # warm-up (thread pool, oneDNN primitives)
     t0 = time.perf_counter()
     y = TP.resnet_forward(t, x, arch)
     one = time.perf_counter() - t0
-    reps = int(max(1, min(8, seconds_budget / max(one, 1e-3) - 1)))
+    reps = int(max(2, min(20, seconds_budget / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(reps):
         y = TP.resnet_forward(t, x, arch)
@@ -121,7 +124,26 @@ def cpu_baseline(arch: str, state, seconds_budget: float = 20.0):
     assert np.isfinite(y.numpy()).all()
     return {"value": round(B * reps / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
             "sample": f"{reps} forwards of batch {B} ({arch} fp32, torch {torch.__version__} "
-                      f"functional port, {threads} threads of {os.cpu_count()} cpus)"}
+                      f"functional port of pytorch_inference.py, {threads} threads of "
+                      f"{os.cpu_count()} host cpus)"}
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the contraction kernel from the committed rocprofv3 --pmc passes
+    (profiles/round*/final_hbm_traffic_pmc.json, made by tools/pmc_traffic.py); counters cannot
+    be read from inside this process, so other configurations report null."""
+    if not (args.arch == "resnet50" and args.batch == 256 and args.dtype == "f32"
+            and args.mode == "fused"):
+        return None
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "final_hbm_traffic_pmc.json")))
+    if not files:
+        return None
+    try:
+        return round(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def summarize_profile(recs, n_forwards: int):
@@ -260,7 +282,7 @@ def main():
                    "parallelism": f"batch split over {world} GPU(s), weights replicated, no collective"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": None,
+                     "traffic": pmc_traffic(args),
                      "kernel": "conv_gemm_kernel (implicit-GEMM conv2d + fc on " +
                                ("v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else "v_mfma_f32_32x32x16_bf16)"),
                      "hbm_GBps": round(g_bytes / (g_ms * 1e-3) / 1e9, 1) if g_ms > 0 else 0.0,
