@@ -94,6 +94,9 @@ RN_API int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on);
  * candidate i (all candidates give bit-identical results; used by rn_model_tune). */
 RN_API int rn_conv_tile_candidates(void);
 RN_API int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate);
+/* Diagnostics: device buffer of 8 x uint64 per block that the contraction kernel fills with
+ * wall-clock stamps of its phases (tools/conv_stamps.py); NULL (default) = off. */
+RN_API int rn_ctx_set_debug_stamps(rn_ctx *ctx, void *dev_buffer);
 RN_API void *rn_ctx_stream(rn_ctx *ctx);
 RN_API int rn_ctx_device(const rn_ctx *ctx);
 RN_API int rn_sync(rn_ctx *ctx);

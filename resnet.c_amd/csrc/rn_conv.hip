@@ -73,7 +73,9 @@ struct GemmParams {
     unsigned total_tiles;  // the grid may be smaller: blocks then walk tiles grid-stride
     int HoWo;
     unsigned mul_hw, shr_hw, mul_w, shr_w;  // n / d == umulhi(n, mul) >> shr for n < 2^31
-    int in_bytes, w_bytes;
+    int in_bytes, w_bytes, out_bytes;
+    // diagnostic only (tools/conv_stamps.py): 8 wall-clock stamps per block, or null
+    unsigned long long *stamps;
 };
 
 typedef __bf16 bf16_t;
@@ -91,7 +93,15 @@ struct Elem<bf16_t> {
     static constexpr int BKE = 64, CH = 8;
 };
 
-constexpr int ROW_FLOATS = 32;  // LDS row = 128 bytes, addressed as 32 dwords
+constexpr int ROW_FLOATS = 32;
+
+// Diagnostic time stamps (100 MHz wall clock) of a block's phases; off unless a debug
+// buffer was attached to the context.  Nothing else reads that buffer.
+__device__ __forceinline__ void stamp(unsigned long long *buf, int slot)
+{
+    if (buf && threadIdx.x == 0) buf[(size_t)blockIdx.x * 8 + slot] = wall_clock64();
+}
+  // LDS row = 128 bytes, addressed as 32 dwords
 
 __device__ __forceinline__ float finish_nores(float v, float sc, float sh, bool has_scale,
                                               bool has_shift, int relu)
@@ -118,6 +128,11 @@ struct OutVec<float> {
     {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(x[j]);
+    }
+    static __device__ __forceinline__ u32x4 pack(const float (&v)[4])
+    {
+        return u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                     __float_as_uint(v[3])};
     }
     static __device__ __forceinline__ void store(void *base, size_t idx, const float (&v)[4])
     {
@@ -146,6 +161,13 @@ struct OutVec<bf16_t> {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
     }
+    static __device__ __forceinline__ u32x4 pack(const float (&v)[8])
+    {
+        bf16x8 x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (bf16_t)v[j];  // round to nearest even
+        return __builtin_bit_cast(u32x4, x);
+    }
     static __device__ __forceinline__ void store(void *base, size_t idx, const float (&v)[8])
     {
         bf16x8 x;
@@ -164,7 +186,8 @@ struct OutVec<bf16_t> {
 };
 
 // T: element type of activations and weights; TO: element type of the output (and residual)
-template <typename T, typename TO, int BM, int BN>
+// PD: K tiles in flight ahead of the one being multiplied (1: one register set; 2: two)
+template <typename T, typename TO, int BM, int BN, int PD>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 {
     constexpr int BKE = Elem<T>::BKE, CH = Elem<T>::CH, ES = (int)sizeof(T);
@@ -179,6 +202,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     // gets the v-th tile of its XCD's contiguous range, N tiles of one M panel adjacent.
     // A block walks v = blockIdx.x, + gridDim.x, ... (persistent when the grid is smaller
     // than the tile count: the next tile's operands are fetched during this tile's epilogue).
+    __builtin_amdgcn_s_setprio(3);
+    stamp(p.stamps, 0);
     const unsigned total_tiles = p.total_tiles;
     auto tile_origin = [&](unsigned v, int &m0_, int &n0_) {
         const unsigned q = total_tiles >> 3, r = total_tiles & 7, xcd = v & 7;
@@ -240,24 +265,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     };
     setup_rows(m0, n0);
 
-    u32x4 ra[AP], rb[BP];
+    u32x4 ra[AP], rb[BP];    // register set 0
+    u32x4 ra1[AP], rb1[BP];  // register set 1 (PD == 2 only)
     int kh = 0, kw = 0, cs = 0;  // K-loop position of the tile being LOADED (wave-uniform)
 
-    auto load_tile = [&](int kt) {
+    // Always issues AP + BP loads (a K tile past the end, or a masked row, just gets an
+    // out-of-range offset): with a fixed number of loads per call hipcc can count exactly
+    // how many younger loads may stay in flight when an older register set is consumed.
+    auto load_tile = [&](int kt, u32x4 (&xa)[AP], u32x4 (&xb)[BP]) {
         const int s_kh = __builtin_amdgcn_readfirstlane(kh);
         const int s_kw = __builtin_amdgcn_readfirstlane(kw);
         const int s_cs = __builtin_amdgcn_readfirstlane(cs);
+        const bool tile_ok = __builtin_amdgcn_readfirstlane(kt) < p.nk;
         const int toff = ((s_kh * p.W + s_kw) * p.Cs + s_cs * BKE) * ES;
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
-            const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
+            const bool ok = tile_ok && ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
             const int voff = ok ? a_off[j] + toff : kOob;
-            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0);
+            xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0);
         }
-        const int soff = __builtin_amdgcn_readfirstlane(kt) * 128;
+        const int soff = tile_ok ? __builtin_amdgcn_readfirstlane(kt) * 128 : 0;
 #pragma unroll
         for (int j = 0; j < BP; ++j)
-            rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_off[j], soff, 0);
+            xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, tile_ok ? b_off[j] : kOob, soff, 0);
         // advance to the next tile: segment fastest, then kw, then kh
         if (++cs == p.cseg) {
             cs = 0;
@@ -268,20 +298,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const u32x4 (&xa)[AP], const u32x4 (&xb)[BP]) {
         float *As = lds + buf * STAGE;
         float *Bs = As + BM * ROW_FLOATS;
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
             const int row = r0 + 32 * j;
             const int pc = c ^ ((row >> 1) & 7);
-            *reinterpret_cast<u32x4 *>(As + row * ROW_FLOATS + pc * 4) = ra[j];
+            *reinterpret_cast<u32x4 *>(As + row * ROW_FLOATS + pc * 4) = xa[j];
         }
 #pragma unroll
         for (int j = 0; j < BP; ++j) {
             const int row = r0 + 32 * j;
             const int pc = c ^ ((row >> 1) & 7);
-            *reinterpret_cast<u32x4 *>(Bs + row * ROW_FLOATS + pc * 4) = rb[j];
+            *reinterpret_cast<u32x4 *>(Bs + row * ROW_FLOATS + pc * 4) = xb[j];
         }
     };
 
@@ -295,6 +325,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     auto compute_tile = [&](int buf) {
         const float *As = lds + buf * STAGE + (wr * (BM / 2) + li) * ROW_FLOATS;
         const float *Bs = lds + buf * STAGE + BM * ROW_FLOATS + (wc * (BN / 2) + li) * ROW_FLOATS;
+        // Issue priority: LOW while this wave streams MFMAs, HIGH for everything else.  A wave
+        // in its prologue / staging / epilogue shares the SIMD with another block's MFMA
+        // stream; at equal priority it got about one instruction per 64-cycle MFMA (stamps:
+        // 8 us for a 300-instruction epilogue), which kept blocks resident 2-3x longer than
+        // their work and starved the matrix pipe of ready blocks.
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             // lane (li, lh) reads chunk 2*ks+lh of its rows: fp32 -> k = 8ks+4lh+{0..3},
@@ -324,6 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
                     }
                 }
         }
+        __builtin_amdgcn_s_setprio(3);
     };
 
     // epilogue geometry: 16 bytes of one output row per thread and pass
@@ -333,52 +370,113 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     constexpr int PASSES = BM / RPP;
     const int cv = t % CV, rr = t / CV;
     const bool vec = (p.Cout % EPT) == 0;  // then n + EPT <= Cout and rows are 16-B aligned
-    u32x4 resv[PASSES];
+    // Everything the epilogue touches goes through range-checked buffer descriptors and is
+    // issued UNCONDITIONALLY (a row past M, a column past Cout or an absent tensor gets an
+    // out-of-range offset / a zero-record descriptor): with conditional loads or stores in
+    // between, hipcc has to assume the fewest younger operations and put vmcnt(0) in front
+    // of every use, which serialised the 8-16 row stores of a tile (stamps: 7-9 us).
+    const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
+    const bool has_res = p.residual != nullptr;
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
+        has_res ? const_cast<void *>(p.residual) : p.out, 0, has_res ? p.out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(
+        has_scale ? (void *)const_cast<float *>(p.scale) : p.out, 0, has_scale ? p.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_sh = __builtin_amdgcn_make_buffer_rsrc(
+        has_shift ? (void *)const_cast<float *>(p.shift) : p.out, 0, has_shift ? p.Cout * 4 : 0, 0x00020000);
+    u32x4 resv[PASSES], scv[EPT / 4], shv[EPT / 4];
 
-    load_tile(0);
-    for (;;) {
-        // the residual tile is fetched now, so that it travels while the K loop runs
+    // residual rows and the channel constants of the CURRENT tile (m0, n0)
+    auto prefetch_epilogue = [&]() {
         const int n = n0 + cv * EPT;
-        const bool res_pre = p.residual != nullptr && vec && n < p.Cout;
-        if (res_pre) {
+        const bool col_ok = vec && n < p.Cout;
 #pragma unroll
-            for (int ps = 0; ps < PASSES; ++ps) {
-                const int m = m0 + rr + ps * RPP;
-                resv[ps] = m < p.M ? OutVec<TO>::load_raw(p.residual, (size_t)m * p.Cout + n)
-                                   : u32x4{0u, 0u, 0u, 0u};
-            }
+        for (int j4 = 0; j4 < EPT / 4; ++j4) {
+            scv[j4] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, col_ok ? (n + 4 * j4) * 4 : kOob, 0, 0);
+            shv[j4] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, col_ok ? (n + 4 * j4) * 4 : kOob, 0, 0);
         }
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int m = m0 + rr + ps * RPP;
+            const int off = (col_ok && m < p.M) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
+            resv[ps] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, off, 0, 0);
+        }
+    };
+
+    load_tile(0, ra, rb);
+    if constexpr (PD == 2) load_tile(1, ra1, rb1);
+    for (;;) {
+        const int n = n0 + cv * EPT;
+        // PD == 1: the residual tile is fetched now, so that it travels while the K loop runs
+        if constexpr (PD == 1) prefetch_epilogue();
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-        store_tile(0);
+        store_tile(0, ra, rb);
         __syncthreads();
-        for (int kt = 0; kt < p.nk; ++kt) {
-            const bool more = kt + 1 < p.nk;
-            if (more) load_tile(kt + 1);
-            compute_tile(kt & 1);
-            if (more) store_tile((kt + 1) & 1);
-            __syncthreads();
-        }
+        if (vtile == blockIdx.x) stamp(p.stamps, 1);  // first operands landed and staged
 
-        // next tile of this block: its first K tile starts travelling before the epilogue
         const unsigned vnext = vtile + gridDim.x;
         const bool has_next = vnext < total_tiles;
         int m0n = 0, n0n = 0;
-        if (has_next) {
-            tile_origin(vnext, m0n, n0n);
-            setup_rows(m0n, n0n);
+        if constexpr (PD == 1) {
+            for (int kt = 0; kt < p.nk; ++kt) {
+                const bool more = kt + 1 < p.nk;
+                if (more) load_tile(kt + 1, ra, rb);
+                compute_tile(kt & 1);
+                if (more) store_tile((kt + 1) & 1, ra, rb);
+                __syncthreads();
+            }
+            // next tile of this block: its first K tile starts travelling before the epilogue
+            if (has_next) {
+                tile_origin(vnext, m0n, n0n);
+                setup_rows(m0n, n0n);
+                kh = kw = cs = 0;
+                load_tile(0, ra, rb);
+            }
+        } else {
+            // tile kt is in LDS buffer kt&1, tile kt+1 in register set (kt+1)&1 (in flight or
+            // landed), tile kt+2 is issued into the set that tile kt just left.  The last
+            // tile is multiplied after the loop, once the next output tile's loads are out.
+            for (int kt = 0;;) {
+                if (kt >= p.nk - 1) break;
+                load_tile(kt + 2, ra, rb);
+                compute_tile(0);
+                store_tile(1, ra1, rb1);
+                __syncthreads();
+                ++kt;
+                if (kt >= p.nk - 1) break;
+                load_tile(kt + 2, ra1, rb1);
+                compute_tile(1);
+                store_tile(0, ra, rb);
+                __syncthreads();
+                ++kt;
+            }
+            prefetch_epilogue();
+            if (has_next) {
+                tile_origin(vnext, m0n, n0n);
+                setup_rows(m0n, n0n);
+            } else {
+#pragma unroll
+                for (int j = 0; j < AP; ++j) a_mask[j] = 0;  // dummy loads: all out of range
+#pragma unroll
+                for (int j = 0; j < BP; ++j) b_off[j] = kOob;
+            }
             kh = kw = cs = 0;
-            load_tile(0);
+            load_tile(0, ra, rb);
+            load_tile(1, ra1, rb1);
+            compute_tile((p.nk - 1) & 1);
+            __syncthreads();  // fragment reads done before the C staging overwrites the ring
         }
 
         // epilogue.  The accumulators go through LDS (free after the K loop) so that global
         // traffic is row-contiguous 16-byte accesses: C/D map of the 32x32 MFMA is
         // col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); a ds_write_b32 of one register
         // puts 32 consecutive columns of two rows, conflict-free.
+        if (vtile == blockIdx.x) stamp(p.stamps, 2);  // K loop done
         float *Cs = lds;  // [BM][BN] fp32
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -388,28 +486,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[mi][ni][e];
         }
+    if (vtile == blockIdx.x) stamp(p.stamps, 5);  // accumulators written to LDS (issued)
     __syncthreads();
+    if (vtile == blockIdx.x) stamp(p.stamps, 6);  // ... by every wave
 
-    if (n < p.Cout) {
-    float sc[EPT], sh[EPT];
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-        sc[j] = 1.f;
-        sh[j] = 0.f;
-        if (n + j < p.Cout) {
-            if (p.scale) sc[j] = p.scale[n + j];
-            if (p.shift) sh[j] = p.shift[n + j];
-        }
-    }
-    const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
     if (vec) {
+        // straight-line: 16-byte LDS read, channel affine, residual, ReLU, 16-byte store per pass
+        float sc[EPT], sh[EPT];
+#pragma unroll
+        for (int j4 = 0; j4 < EPT / 4; ++j4)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sc[4 * j4 + j] = has_scale ? __uint_as_float(scv[j4][j]) : 1.f;
+                // -0.0 as the neutral addend keeps a -0.0 convolution result bit-exact
+                sh[4 * j4 + j] = has_shift ? __uint_as_float(shv[j4][j]) : -0.f;
+            }
+        const bool col_ok = n < p.Cout;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = rr + ps * RPP;
             const int m = m0 + row;
-            if (m >= p.M) continue;
             float v[EPT], res[EPT];
-            if (p.residual) OutVec<TO>::unpack(resv[ps], res);
+            OutVec<TO>::unpack(resv[ps], res);
 #pragma unroll
             for (int j4 = 0; j4 < EPT / 4; ++j4) {
                 const float4 x = *reinterpret_cast<const float4 *>(Cs + row * BN + cv * EPT + 4 * j4);
@@ -417,23 +515,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
             }
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
-                if (p.residual) {
-                    float y = v[j];
-                    if (has_scale) {
-                        y = fmaf(y, sc[j], sh[j]);
-                    } else if (has_shift) {
-                        y += sh[j];
-                    }
-                    y += res[j];
-                    v[j] = p.relu ? fmaxf(y, 0.f) : y;
-                } else {
-                    // no "+ 0.f": keeps -0.0 results of the plain convolution bit-exact
-                    v[j] = finish_nores(v[j], sc[j], sh[j], has_scale, has_shift, p.relu);
-                }
+                float y = fmaf(v[j], sc[j], sh[j]);
+                y = has_res ? y + res[j] : y;
+                v[j] = p.relu ? fmaxf(y, 0.f) : y;
             }
-            OutVec<TO>::store(p.out, (size_t)m * p.Cout + n, v);
+            const int off = (col_ok && m < p.M) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
+            __builtin_amdgcn_raw_buffer_store_b128(OutVec<TO>::pack(v), rsrc_o, off, 0, 0);
         }
-    } else {
+    } else if (n < p.Cout) {
+        // ragged channel count (Cout % EPT != 0): element-wise, rare
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = rr + ps * RPP;
             const int m = m0 + row;
@@ -442,22 +532,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
                 if (n + j >= p.Cout) break;
                 const size_t o = (size_t)m * p.Cout + n + j;
                 float y = Cs[row * BN + cv * EPT + j];
-                if (p.residual) {
-                    if (has_scale) {
-                        y = fmaf(y, sc[j], sh[j]);
-                    } else if (has_shift) {
-                        y += sh[j];
-                    }
-                    y += OutVec<TO>::load1(p.residual, o);
-                    y = p.relu ? fmaxf(y, 0.f) : y;
-                } else {
-                    y = finish_nores(y, sc[j], sh[j], has_scale, has_shift, p.relu);
-                }
+                y = fmaf(y, has_scale ? p.scale[n + j] : 1.f, has_shift ? p.shift[n + j] : -0.f);
+                if (has_res) y += OutVec<TO>::load1(p.residual, o);
+                y = p.relu ? fmaxf(y, 0.f) : y;
                 OutVec<TO>::store1(p.out, o, y);
             }
         }
     }
-    }  // n < Cout
+        if (p.stamps && vtile == blockIdx.x) {
+            stamp(p.stamps, 3);  // epilogue stores issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(p.stamps, 4);  // ... and acknowledged
+        }
         if (!has_next) break;
         __syncthreads();  // the C staging area becomes operand stage 0 again
         vtile = vnext;
@@ -555,14 +641,14 @@ void fast_div(unsigned d, unsigned *mul, unsigned *shr)
 }
 
 // Blocks of one instantiation that fit a CU at once (registers and LDS), asked once.
-template <typename T, typename TO, int BM, int BN>
+template <typename T, typename TO, int BM, int BN, int PD>
 int resident_blocks_per_cu()
 {
     static int cached = 0;
     if (cached == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_kernel<T, TO, BM, BN>, 256,
-                                                         0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &nb, conv_gemm_kernel<T, TO, BM, BN, PD>, 256, 0) != hipSuccess ||
             nb < 1)
             nb = 1;
         cached = nb;
@@ -570,28 +656,37 @@ int resident_blocks_per_cu()
     return cached;
 }
 
-template <typename T, typename TO, int BM, int BN>
+template <typename T, typename TO, int BM, int BN, int PD>
 void launch_one(rn_ctx *ctx, GemmParams &p, bool persistent)
 {
     unsigned grid = p.total_tiles;
     if (persistent) {
-        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN>();
+        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN, PD>();
         if (grid > slots) grid = slots;
     }
-    conv_gemm_kernel<T, TO, BM, BN><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
+    conv_gemm_kernel<T, TO, BM, BN, PD><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
+}
+
+template <typename T, typename TO, int PD>
+void launch_shape(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent)
+{
+    if (BMsel == 128 && BNsel == 128)
+        launch_one<T, TO, 128, 128, PD>(ctx, p, persistent);
+    else if (BMsel == 128 && BNsel == 64)
+        launch_one<T, TO, 128, 64, PD>(ctx, p, persistent);
+    else if (BMsel == 64 && BNsel == 128)
+        launch_one<T, TO, 64, 128, PD>(ctx, p, persistent);
+    else
+        launch_one<T, TO, 64, 64, PD>(ctx, p, persistent);
 }
 
 template <typename T, typename TO>
-void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent)
+void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent, int pd)
 {
-    if (BMsel == 128 && BNsel == 128)
-        launch_one<T, TO, 128, 128>(ctx, p, persistent);
-    else if (BMsel == 128 && BNsel == 64)
-        launch_one<T, TO, 128, 64>(ctx, p, persistent);
-    else if (BMsel == 64 && BNsel == 128)
-        launch_one<T, TO, 64, 128>(ctx, p, persistent);
+    if (pd == 2)
+        launch_shape<T, TO, 2>(ctx, p, BMsel, BNsel, persistent);
     else
-        launch_one<T, TO, 64, 64>(ctx, p, persistent);
+        launch_shape<T, TO, 1>(ctx, p, BMsel, BNsel, persistent);
 }
 
 // GEMM launch on NHWC data with packed weights.  Caller has checked eligibility.
@@ -631,8 +726,10 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     p.HoWo = p.Ho * p.Wo;
     fast_div((unsigned)p.HoWo, &p.mul_hw, &p.shr_hw);
     fast_div((unsigned)p.Wo, &p.mul_w, &p.shr_w);
+    p.stamps = (unsigned long long *)ctx->debug_stamps;
     p.in_bytes = (int)(B * H * W * (uint64_t)p.Cs * es);
     p.w_bytes = (int)(Cout * (uint64_t)p.Ktot * es);
+    p.out_bytes = (int)(B * h_out * w_out * Cout * (uint64_t)(dt_out == RN_DTYPE_BF16 ? 2 : 4));
 
     // tile choice: the contraction is matrix-core bound, so a launch takes about
     // ceil(tiles / 256 CUs) rounds of one tile's MFMA time; pick the candidate with the
@@ -642,11 +739,14 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     static const double cand_eff[4] = {1.00, 0.94, 0.94, 0.86};
     int BMsel = 128, BNsel = 128;
     bool persistent;
-    if (ctx->conv_tile >= 1 && ctx->conv_tile <= 8) {
-        // candidates 1-4: one block per tile; 5-8: the same tiles walked by a resident grid
+    int pd = 1;
+    if (ctx->conv_tile >= 1 && ctx->conv_tile <= 12) {
+        // candidates 1-4: one block per tile; 5-8: the same tiles walked by a resident grid;
+        // 9-12: resident grid with two K tiles in flight (two register sets)
         BMsel = cand[(ctx->conv_tile - 1) & 3][0];
         BNsel = cand[(ctx->conv_tile - 1) & 3][1];
         persistent = ctx->conv_tile > 4;
+        pd = ctx->conv_tile > 8 ? 2 : 1;
     } else {
         double best = 1e300;
         for (int ci = 0; ci < 4; ++ci) {
@@ -669,11 +769,11 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     RN_REQUIRE(ctx, fits_i32(total), "too many tiles");
     p.total_tiles = (unsigned)total;
     if (dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)
-        launch_tiles<float, float>(ctx, p, BMsel, BNsel, persistent);
+        launch_tiles<float, float>(ctx, p, BMsel, BNsel, persistent, pd);
     else if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_BF16)
-        launch_tiles<bf16_t, bf16_t>(ctx, p, BMsel, BNsel, persistent);
+        launch_tiles<bf16_t, bf16_t>(ctx, p, BMsel, BNsel, persistent, pd);
     else if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_F32)
-        launch_tiles<bf16_t, float>(ctx, p, BMsel, BNsel, persistent);
+        launch_tiles<bf16_t, float>(ctx, p, BMsel, BNsel, persistent, pd);
     else
         return rn_set_error(ctx, RN_ERR_UNSUPPORTED, "%s: dtype combination %d -> %d", what, dt_in,
                             dt_out);
@@ -726,10 +826,11 @@ int check_conv_args(rn_ctx *ctx, const float *inp, const float *out, const float
 }
 
 bool gemm_eligible(const void *inp, const void *out, const void *w, uint64_t Cin, uint64_t k,
-                   uint64_t in_elems, uint64_t w_elems)
+                   uint64_t in_elems, uint64_t w_elems, uint64_t out_elems)
 {
     // buffer descriptors carry byte counts below 2^31
-    if (in_elems >= (1ull << 29) || w_elems >= (1ull << 29)) return false;
+    if (in_elems >= (1ull << 29) || w_elems >= (1ull << 29) || out_elems >= (1ull << 29))
+        return false;
     const bool al = ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out) |
                       reinterpret_cast<uintptr_t>(w)) & 15) == 0;
     return al && k <= 15 && (Cin % 32 == 0 || rn_conv_is_c4(Cin, k));
@@ -754,7 +855,8 @@ int rn_conv2d_nhwc_forward(rn_ctx *ctx, const float *inp, float *out, const floa
                    "misaligned residual");
     if (gemm_eligible(inp, out, packed_weight, in_channels, kernel_size,
                       B * H * W * rn_conv2d_input_channels(in_channels),
-                      rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size))) {
+                      rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size),
+                      B * h_out * w_out * out_channels)) {
         return launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, inp, out, packed_weight, kernel_size,
                            stride, padding, h_out, w_out, B, in_channels, out_channels, H, W,
                            epilogue, "rn_conv2d_nhwc_forward");
@@ -778,6 +880,7 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
     const bool c4 = rn_conv_is_c4(in_channels, kernel_size);
     const bool fast = (in_channels % 32 == 0 || c4) && kernel_size <= 15 &&
                       B * H * W * rn_conv2d_input_channels(in_channels) < (1ull << 29) &&
+                      B * h_out * w_out * out_channels < (1ull << 29) &&
                       rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size) <
                           (1ull << 29);
     if (!fast || (ctx->layout == RN_LAYOUT_NHWC && in_channels < 4)) {
@@ -844,7 +947,7 @@ int rn_conv2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void 
     }
     const uint64_t ktot = c4 ? kernel_size * 64 : kernel_size * kernel_size * in_channels;
     RN_REQUIRE(ctx, B * H * W * cs < (1ull << 30) && out_channels * ktot < (1ull << 30) &&
-                        fits_i32(B * h_out * w_out * out_channels),
+                        B * h_out * w_out * out_channels < (1ull << 29),
                "tensor too large");
     RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out) |
                       reinterpret_cast<uintptr_t>(packed_weight)) & 15) == 0,
@@ -868,7 +971,8 @@ int rn_linear_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
     rn_epilogue ep = {nullptr, bias, nullptr, 0};
     // W is [out][in] row-major == the K-major panel of a 1x1 convolution on a 1x1 image
     if (in_features % 32 == 0 &&
-        gemm_eligible(inp, out, weight, in_features, 1, B * in_features, out_features * in_features)) {
+        gemm_eligible(inp, out, weight, in_features, 1, B * in_features, out_features * in_features,
+                      B * out_features)) {
         return launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, inp, out, weight, 1, 1, 0, 1, 1, B,
                            in_features, out_features, 1, 1, &ep, "rn_linear_forward");
     }

@@ -145,7 +145,14 @@ int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate)
     return RN_OK;
 }
 
-int rn_conv_tile_candidates(void) { return 8; }
+int rn_conv_tile_candidates(void) { return 12; }
+
+int rn_ctx_set_debug_stamps(rn_ctx *ctx, void *dev_buffer)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    ctx->debug_stamps = dev_buffer;
+    return RN_OK;
+}
 
 void *rn_ctx_stream(rn_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int rn_ctx_device(const rn_ctx *ctx) { return ctx ? ctx->device : -1; }

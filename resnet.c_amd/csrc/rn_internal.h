@@ -14,7 +14,8 @@ struct rn_ctx {
     bool own_stream;
     int layout;
     int sync_each_op;
-    int conv_tile;  // 0 = choose per launch, 1..4 = force candidate (tuning)
+    int conv_tile;  // 0 = choose per launch, 1..N = force candidate (tuning)
+    void *debug_stamps;  // diagnostic phase stamps of the contraction kernel, normally null
     // scratch grown on demand (never inside a graph capture; callers that capture
     // warm up first so the sizes are already settled)
     void *scratch[4];

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the contraction kernel's blocks from in-kernel wall-clock stamps.
+
+    python tools/conv_stamps.py B H W Cin Cout k stride pad --cand 1 [--dtype bf16] [--residual]
+Stamps (100 MHz): 0 block start, 1 first operands staged, 2 K loop done, 3 epilogue stores
+issued, 4 stores acknowledged.  Prints medians in microseconds over all blocks."""
+import argparse, ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import resnet_c_amd as R
+from resnet_c_amd import _lib as L
+from resnet_c_amd.tensor import _DeviceBuffer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("dims", type=int, nargs=8)
+ap.add_argument("--cand", type=int, default=1)
+ap.add_argument("--dtype", default="f32")
+ap.add_argument("--residual", action="store_true")
+a = ap.parse_args()
+B, H, W, Cin, Cout, k, s, p = a.dims
+lib, ctx = L.lib(), R.get_ctx()
+dt = L.RN_DTYPE_BF16 if a.dtype == "bf16" else L.RN_DTYPE_F32
+es = 2 if a.dtype == "bf16" else 4
+ho, wo = int(lib.rn_conv_output_size(H, k, s, p)), int(lib.rn_conv_output_size(W, k, s, p))
+rng = np.random.default_rng(0)
+def buf(n):
+    b = _DeviceBuffer(ctx, n * es)
+    h = rng.standard_normal(n, dtype=np.float32) * 0.5
+    if es == 2: h = R.ops.to_bf16_bits(h)
+    L.check(lib.rn_memcpy_h2d(ctx.handle, b.ptr, h.ctypes.data, h.nbytes), "h2d", ctx.handle)
+    return b
+x = buf(B * H * W * Cin); wn = int(lib.rn_conv2d_packed_weight_numel_dt(dt, Cin, Cout, k)); w = buf(wn)
+out = _DeviceBuffer(ctx, B * ho * wo * Cout * es); res = buf(B * ho * wo * Cout) if a.residual else None
+sc = R.FloatTensor.from_numpy(np.ones(Cout, np.float32), R.Device.GPU)
+ep = L.Epilogue(sc.data(), sc.data(), res.ptr if res else None, 1)
+nblk = 1 << 16
+st = _DeviceBuffer(ctx, nblk * 64)
+lib.rn_ctx_set_conv_tile(ctx.handle, a.cand)
+def run():
+    L.check(lib.rn_conv2d_nhwc_forward_dt(ctx.handle, dt, dt, x.ptr, out.ptr, w.ptr, k, s, p, ho, wo, B, Cin, Cout, H, W, ctypes.byref(ep)), "conv", ctx.handle)
+run(); run(); ctx.sync()
+lib.rn_memset(ctx.handle, st.ptr, 0, nblk * 64)
+lib.rn_ctx_set_debug_stamps(ctx.handle, st.ptr)
+run(); ctx.sync()
+lib.rn_ctx_set_debug_stamps(ctx.handle, None)
+raw = np.empty(nblk * 8, dtype=np.uint64)
+lib.rn_memcpy_d2h(ctx.handle, raw.ctypes.data, st.ptr, raw.nbytes)
+full = raw.reshape(nblk, 8).astype(np.float64)
+t = full[:, :5]
+keep = t[:, 0] > 0
+full = full[keep]
+t = t[keep]
+us = t / 100.0
+d = np.diff(us, axis=1)
+print(f"blocks {len(t)}  kernel span {(us[:,4].max()-us[:,0].min()):.1f} us")
+for i, name in enumerate(["start->operands staged", "K loop (+next-tile prefetch)", "epilogue until stores issued", "stores acknowledged"]):
+    print(f"  {name:32s} median {np.median(d[:, i]):7.2f} us   p90 {np.percentile(d[:, i], 90):7.2f}")
+print(f"  block lifetime                   median {np.median(us[:,4]-us[:,0]):7.2f} us")
+
+if full[:, 5].max() > 0:
+    print(f"  epilogue: K-loop end -> acc in LDS issued   median {np.median(full[:,5]-full[:,2])/100:7.2f} us")
+    print(f"  epilogue: barrier                           median {np.median(full[:,6]-full[:,5])/100:7.2f} us")
+    print(f"  epilogue: read back + stores issued         median {np.median(full[:,3]-full[:,6])/100:7.2f} us")
