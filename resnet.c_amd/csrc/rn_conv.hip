@@ -186,8 +186,7 @@ struct OutVec<bf16_t> {
 };
 
 // T: element type of activations and weights; TO: element type of the output (and residual)
-// PD: K tiles in flight ahead of the one being multiplied (1: one register set; 2: two)
-template <typename T, typename TO, int BM, int BN, int PD>
+template <typename T, typename TO, int BM, int BN>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 {
     constexpr int BKE = Elem<T>::BKE, CH = Elem<T>::CH, ES = (int)sizeof(T);
@@ -265,29 +264,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     };
     setup_rows(m0, n0);
 
-    u32x4 ra[AP], rb[BP];    // register set 0
-    u32x4 ra1[AP], rb1[BP];  // register set 1 (PD == 2 only)
+    u32x4 ra[AP], rb[BP];
     int kh = 0, kw = 0, cs = 0;  // K-loop position of the tile being LOADED (wave-uniform)
 
-    // Always issues AP + BP loads (a K tile past the end, or a masked row, just gets an
-    // out-of-range offset): with a fixed number of loads per call hipcc can count exactly
-    // how many younger loads may stay in flight when an older register set is consumed.
+    // always AP + BP loads, never a branch: a masked row just gets an out-of-range offset
     auto load_tile = [&](int kt, u32x4 (&xa)[AP], u32x4 (&xb)[BP]) {
         const int s_kh = __builtin_amdgcn_readfirstlane(kh);
         const int s_kw = __builtin_amdgcn_readfirstlane(kw);
         const int s_cs = __builtin_amdgcn_readfirstlane(cs);
-        const bool tile_ok = __builtin_amdgcn_readfirstlane(kt) < p.nk;
         const int toff = ((s_kh * p.W + s_kw) * p.Cs + s_cs * BKE) * ES;
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
-            const bool ok = tile_ok && ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
+            const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
             const int voff = ok ? a_off[j] + toff : kOob;
             xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0);
         }
-        const int soff = tile_ok ? __builtin_amdgcn_readfirstlane(kt) * 128 : 0;
+        const int soff = __builtin_amdgcn_readfirstlane(kt) * 128;
 #pragma unroll
         for (int j = 0; j < BP; ++j)
-            xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, tile_ok ? b_off[j] : kOob, soff, 0);
+            xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_off[j], soff, 0);
         // advance to the next tile: segment fastest, then kw, then kh
         if (++cs == p.cseg) {
             cs = 0;
@@ -385,6 +380,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     const __amdgpu_buffer_rsrc_t rsrc_sh = __builtin_amdgcn_make_buffer_rsrc(
         has_shift ? (void *)const_cast<float *>(p.shift) : p.out, 0, has_shift ? p.Cout * 4 : 0, 0x00020000);
     u32x4 resv[PASSES], scv[EPT / 4], shv[EPT / 4];
+    // Fetching the residual tile before the K loop hides its latency completely, but its
+    // registers stay live across the loop; with 16 passes (fp32 128x128: 64 VGPRs) that
+    // squeezed the fragment registers and exposed LDS latency inside the MFMA stream, so
+    // large tiles fetch it at the start of the epilogue instead (the accumulators are dead
+    // by then).
+    constexpr bool EARLY_RES = PASSES <= 8;
 
     // residual rows and the channel constants of the CURRENT tile (m0, n0)
     auto prefetch_epilogue = [&]() {
@@ -403,12 +404,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         }
     };
 
+    stamp(p.stamps, 7);  // block set up, first loads about to be issued
     load_tile(0, ra, rb);
-    if constexpr (PD == 2) load_tile(1, ra1, rb1);
     for (;;) {
         const int n = n0 + cv * EPT;
-        // PD == 1: the residual tile is fetched now, so that it travels while the K loop runs
-        if constexpr (PD == 1) prefetch_epilogue();
+        // the residual tile and the channel constants travel while the K loop runs
+        if constexpr (EARLY_RES) prefetch_epilogue();
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -422,54 +423,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         const unsigned vnext = vtile + gridDim.x;
         const bool has_next = vnext < total_tiles;
         int m0n = 0, n0n = 0;
-        if constexpr (PD == 1) {
-            for (int kt = 0; kt < p.nk; ++kt) {
-                const bool more = kt + 1 < p.nk;
-                if (more) load_tile(kt + 1, ra, rb);
-                compute_tile(kt & 1);
-                if (more) store_tile((kt + 1) & 1, ra, rb);
-                __syncthreads();
-            }
-            // next tile of this block: its first K tile starts travelling before the epilogue
-            if (has_next) {
-                tile_origin(vnext, m0n, n0n);
-                setup_rows(m0n, n0n);
-                kh = kw = cs = 0;
-                load_tile(0, ra, rb);
-            }
-        } else {
-            // tile kt is in LDS buffer kt&1, tile kt+1 in register set (kt+1)&1 (in flight or
-            // landed), tile kt+2 is issued into the set that tile kt just left.  The last
-            // tile is multiplied after the loop, once the next output tile's loads are out.
-            for (int kt = 0;;) {
-                if (kt >= p.nk - 1) break;
-                load_tile(kt + 2, ra, rb);
-                compute_tile(0);
-                store_tile(1, ra1, rb1);
-                __syncthreads();
-                ++kt;
-                if (kt >= p.nk - 1) break;
-                load_tile(kt + 2, ra1, rb1);
-                compute_tile(1);
-                store_tile(0, ra, rb);
-                __syncthreads();
-                ++kt;
-            }
-            prefetch_epilogue();
-            if (has_next) {
-                tile_origin(vnext, m0n, n0n);
-                setup_rows(m0n, n0n);
-            } else {
-#pragma unroll
-                for (int j = 0; j < AP; ++j) a_mask[j] = 0;  // dummy loads: all out of range
-#pragma unroll
-                for (int j = 0; j < BP; ++j) b_off[j] = kOob;
-            }
+        for (int kt = 0; kt < p.nk; ++kt) {
+            const bool more = kt + 1 < p.nk;
+            if (more) load_tile(kt + 1, ra, rb);
+            compute_tile(kt & 1);
+            if (more) store_tile((kt + 1) & 1, ra, rb);
+            __syncthreads();
+        }
+        // next tile of this block: its first K tile starts travelling before the epilogue
+        if (has_next) {
+            tile_origin(vnext, m0n, n0n);
+            setup_rows(m0n, n0n);
             kh = kw = cs = 0;
             load_tile(0, ra, rb);
-            load_tile(1, ra1, rb1);
-            compute_tile((p.nk - 1) & 1);
-            __syncthreads();  // fragment reads done before the C staging overwrites the ring
         }
 
         // epilogue.  The accumulators go through LDS (free after the K loop) so that global
@@ -486,6 +452,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[mi][ni][e];
         }
+    if constexpr (!EARLY_RES) prefetch_epilogue();
     if (vtile == blockIdx.x) stamp(p.stamps, 5);  // accumulators written to LDS (issued)
     __syncthreads();
     if (vtile == blockIdx.x) stamp(p.stamps, 6);  // ... by every wave
@@ -641,14 +608,14 @@ void fast_div(unsigned d, unsigned *mul, unsigned *shr)
 }
 
 // Blocks of one instantiation that fit a CU at once (registers and LDS), asked once.
-template <typename T, typename TO, int BM, int BN, int PD>
+template <typename T, typename TO, int BM, int BN>
 int resident_blocks_per_cu()
 {
     static int cached = 0;
     if (cached == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-                &nb, conv_gemm_kernel<T, TO, BM, BN, PD>, 256, 0) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_kernel<T, TO, BM, BN>, 256,
+                                                         0) != hipSuccess ||
             nb < 1)
             nb = 1;
         cached = nb;
@@ -656,37 +623,28 @@ int resident_blocks_per_cu()
     return cached;
 }
 
-template <typename T, typename TO, int BM, int BN, int PD>
+template <typename T, typename TO, int BM, int BN>
 void launch_one(rn_ctx *ctx, GemmParams &p, bool persistent)
 {
     unsigned grid = p.total_tiles;
     if (persistent) {
-        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN, PD>();
+        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN>();
         if (grid > slots) grid = slots;
     }
-    conv_gemm_kernel<T, TO, BM, BN, PD><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
-}
-
-template <typename T, typename TO, int PD>
-void launch_shape(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent)
-{
-    if (BMsel == 128 && BNsel == 128)
-        launch_one<T, TO, 128, 128, PD>(ctx, p, persistent);
-    else if (BMsel == 128 && BNsel == 64)
-        launch_one<T, TO, 128, 64, PD>(ctx, p, persistent);
-    else if (BMsel == 64 && BNsel == 128)
-        launch_one<T, TO, 64, 128, PD>(ctx, p, persistent);
-    else
-        launch_one<T, TO, 64, 64, PD>(ctx, p, persistent);
+    conv_gemm_kernel<T, TO, BM, BN><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
 }
 
 template <typename T, typename TO>
-void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent, int pd)
+void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent)
 {
-    if (pd == 2)
-        launch_shape<T, TO, 2>(ctx, p, BMsel, BNsel, persistent);
+    if (BMsel == 128 && BNsel == 128)
+        launch_one<T, TO, 128, 128>(ctx, p, persistent);
+    else if (BMsel == 128 && BNsel == 64)
+        launch_one<T, TO, 128, 64>(ctx, p, persistent);
+    else if (BMsel == 64 && BNsel == 128)
+        launch_one<T, TO, 64, 128>(ctx, p, persistent);
     else
-        launch_shape<T, TO, 1>(ctx, p, BMsel, BNsel, persistent);
+        launch_one<T, TO, 64, 64>(ctx, p, persistent);
 }
 
 // GEMM launch on NHWC data with packed weights.  Caller has checked eligibility.
@@ -739,14 +697,11 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     static const double cand_eff[4] = {1.00, 0.94, 0.94, 0.86};
     int BMsel = 128, BNsel = 128;
     bool persistent;
-    int pd = 1;
-    if (ctx->conv_tile >= 1 && ctx->conv_tile <= 12) {
-        // candidates 1-4: one block per tile; 5-8: the same tiles walked by a resident grid;
-        // 9-12: resident grid with two K tiles in flight (two register sets)
+    if (ctx->conv_tile >= 1 && ctx->conv_tile <= 8) {
+        // candidates 1-4: one block per tile; 5-8: the same tiles walked by a resident grid
         BMsel = cand[(ctx->conv_tile - 1) & 3][0];
         BNsel = cand[(ctx->conv_tile - 1) & 3][1];
         persistent = ctx->conv_tile > 4;
-        pd = ctx->conv_tile > 8 ? 2 : 1;
     } else {
         double best = 1e300;
         for (int ci = 0; ci < 4; ++ci) {
@@ -769,11 +724,11 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     RN_REQUIRE(ctx, fits_i32(total), "too many tiles");
     p.total_tiles = (unsigned)total;
     if (dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)
-        launch_tiles<float, float>(ctx, p, BMsel, BNsel, persistent, pd);
+        launch_tiles<float, float>(ctx, p, BMsel, BNsel, persistent);
     else if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_BF16)
-        launch_tiles<bf16_t, bf16_t>(ctx, p, BMsel, BNsel, persistent, pd);
+        launch_tiles<bf16_t, bf16_t>(ctx, p, BMsel, BNsel, persistent);
     else if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_F32)
-        launch_tiles<bf16_t, float>(ctx, p, BMsel, BNsel, persistent, pd);
+        launch_tiles<bf16_t, float>(ctx, p, BMsel, BNsel, persistent);
     else
         return rn_set_error(ctx, RN_ERR_UNSUPPORTED, "%s: dtype combination %d -> %d", what, dt_in,
                             dt_out);

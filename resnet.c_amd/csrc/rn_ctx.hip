@@ -145,7 +145,7 @@ int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate)
     return RN_OK;
 }
 
-int rn_conv_tile_candidates(void) { return 12; }
+int rn_conv_tile_candidates(void) { return 8; }
 
 int rn_ctx_set_debug_stamps(rn_ctx *ctx, void *dev_buffer)
 {

@@ -49,8 +49,7 @@ def main():
     lib.rn_event_create(ctx.handle, ctypes.byref(e0)); lib.rn_event_create(ctx.handle, ctypes.byref(e1))
     flops = 2.0 * B * ho * wo * Cout * Cin * k * k
     bytes_ = es * (B * H * W * Cin + wn + B * ho * wo * Cout * (2 if a.residual else 1))
-    names = ["auto", "128x128", "128x64", "64x128", "64x64", "P128x128", "P128x64", "P64x128", "P64x64",
-             "D128x128", "D128x64", "D64x128", "D64x64"]
+    names = ["auto", "128x128", "128x64", "64x128", "64x64", "P128x128", "P128x64", "P64x128", "P64x64"]
     for cand in range(0, lib.rn_conv_tile_candidates() + 1):
         lib.rn_ctx_set_conv_tile(ctx.handle, cand)
         def run():

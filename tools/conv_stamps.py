@@ -61,3 +61,6 @@ if full[:, 5].max() > 0:
     print(f"  epilogue: K-loop end -> acc in LDS issued   median {np.median(full[:,5]-full[:,2])/100:7.2f} us")
     print(f"  epilogue: barrier                           median {np.median(full[:,6]-full[:,5])/100:7.2f} us")
     print(f"  epilogue: read back + stores issued         median {np.median(full[:,3]-full[:,6])/100:7.2f} us")
+if full[:, 7].max() > 0:
+    print(f"  prologue: start -> set-up done              median {np.median(full[:,7]-full[:,0])/100:7.2f} us")
+    print(f"  prologue: loads issued -> staged + barrier  median {np.median(full[:,1]-full[:,7])/100:7.2f} us")
