@@ -189,7 +189,7 @@ struct OutVec<bf16_t> {
 template <typename T, typename TO, int BM, int BN>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 {
-    constexpr int BKE = Elem<T>::BKE, CH = Elem<T>::CH, ES = (int)sizeof(T);
+    constexpr int CH = Elem<T>::CH, ES = (int)sizeof(T);
     constexpr int AP = BM / 32;  // A rows staged per thread
     constexpr int BP = BN / 32;
     constexpr int MI = BM / 64;  // 32x32 tiles per wave along M
@@ -266,19 +266,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 
     u32x4 ra[AP], rb[BP];
     int kh = 0, kw = 0, cs = 0;  // K-loop position of the tile being LOADED (wave-uniform)
+    int a_cur[AP];               // byte offset of the current tap's first segment, or kOob
 
-    // always AP + BP loads, never a branch: a masked row just gets an out-of-range offset
+    // always AP + BP loads, never a branch around a load: a masked row just gets an
+    // out-of-range offset.  The per-row offset only changes with the tap (kh, kw); the
+    // 128-byte segments of one tap are walked through the scalar offset, so a K tile inside
+    // a tap costs no vector ALU work at all.
     auto load_tile = [&](int kt, u32x4 (&xa)[AP], u32x4 (&xb)[BP]) {
-        const int s_kh = __builtin_amdgcn_readfirstlane(kh);
-        const int s_kw = __builtin_amdgcn_readfirstlane(kw);
         const int s_cs = __builtin_amdgcn_readfirstlane(cs);
-        const int toff = ((s_kh * p.W + s_kw) * p.Cs + s_cs * BKE) * ES;
+        if (s_cs == 0) {
+            const int s_kh = __builtin_amdgcn_readfirstlane(kh);
+            const int s_kw = __builtin_amdgcn_readfirstlane(kw);
+            const int toff = (s_kh * p.W + s_kw) * p.Cs * ES;
 #pragma unroll
-        for (int j = 0; j < AP; ++j) {
-            const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
-            const int voff = ok ? a_off[j] + toff : kOob;
-            xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, voff, 0, 0);
+            for (int j = 0; j < AP; ++j) {
+                const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
+                a_cur[j] = ok ? a_off[j] + toff : kOob;
+            }
         }
+        const int seg = s_cs * 128;
+#pragma unroll
+        for (int j = 0; j < AP; ++j)
+            xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_cur[j], seg, 0);
         const int soff = __builtin_amdgcn_readfirstlane(kt) * 128;
 #pragma unroll
         for (int j = 0; j < BP; ++j)
