@@ -86,11 +86,11 @@ template <typename T>
 struct Elem;
 template <>
 struct Elem<float> {
-    static constexpr int BKE = 32, CH = 4;
+    static constexpr int CH = 4;
 };
 template <>
 struct Elem<bf16_t> {
-    static constexpr int BKE = 64, CH = 8;
+    static constexpr int CH = 8;
 };
 
 constexpr int ROW_FLOATS = 32;
