@@ -42,6 +42,8 @@
 // Shapes the GEMM cannot take (Cin not a multiple of 32 and not the small-Cin stem
 // form) run a direct kernel that keeps the reference's exact summation order
 // ic -> kh -> kw.
+#include <type_traits>
+
 #include "rn_internal.h"
 
 bool rn_conv_is_c4(uint64_t Cin, uint64_t k);
@@ -73,6 +75,7 @@ struct GemmParams {
     unsigned total_tiles;  // the grid may be smaller: blocks then walk tiles grid-stride
     int HoWo;
     unsigned mul_hw, shr_hw, mul_w, shr_w;  // n / d == umulhi(n, mul) >> shr for n < 2^31
+    unsigned mul_cs, shr_cs, mul_kw, shr_kw;  // K tile -> (tap, segment), tap -> (kh, kw)
     int in_bytes, w_bytes, out_bytes;
     // diagnostic only (tools/conv_stamps.py): 8 wall-clock stamps per block, or null
     unsigned long long *stamps;
@@ -265,18 +268,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     setup_rows(m0, n0);
 
     u32x4 ra[AP], rb[BP];
-    int kh = 0, kw = 0, cs = 0;  // K-loop position of the tile being LOADED (wave-uniform)
-    int a_cur[AP];               // byte offset of the current tap's first segment, or kOob
+    int a_cur[AP];  // byte offset of the current tap's first segment, or kOob
 
     // always AP + BP loads, never a branch around a load: a masked row just gets an
-    // out-of-range offset.  The per-row offset only changes with the tap (kh, kw); the
-    // 128-byte segments of one tap are walked through the scalar offset, so a K tile inside
-    // a tap costs no vector ALU work at all.
+    // out-of-range offset.  The K position (kh, kw, segment) is derived from the tile index
+    // with scalar arithmetic; the per-row offset only changes with the tap, and the 128-byte
+    // segments of one tap are walked through the scalar offset, so a K tile inside a tap
+    // costs no vector ALU work at all (vector ALU work competes with the fp32 MFMA stream).
     auto load_tile = [&](int kt, u32x4 (&xa)[AP], u32x4 (&xb)[BP]) {
-        const int s_cs = __builtin_amdgcn_readfirstlane(cs);
+        const unsigned s_kt = (unsigned)__builtin_amdgcn_readfirstlane(kt);
+        const unsigned tap = p.cseg == 1 ? s_kt : (__umulhi(s_kt, p.mul_cs) >> p.shr_cs);
+        const int s_cs = (int)(s_kt - tap * (unsigned)p.cseg);
         if (s_cs == 0) {
-            const int s_kh = __builtin_amdgcn_readfirstlane(kh);
-            const int s_kw = __builtin_amdgcn_readfirstlane(kw);
+            const unsigned ukh = p.KW == 1 ? tap : (__umulhi(tap, p.mul_kw) >> p.shr_kw);
+            const int s_kh = (int)ukh, s_kw = (int)(tap - ukh * (unsigned)p.KW);
             const int toff = (s_kh * p.W + s_kw) * p.Cs * ES;
 #pragma unroll
             for (int j = 0; j < AP; ++j) {
@@ -288,36 +293,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 #pragma unroll
         for (int j = 0; j < AP; ++j)
             xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_cur[j], seg, 0);
-        const int soff = __builtin_amdgcn_readfirstlane(kt) * 128;
+        const int soff = (int)s_kt * 128;
 #pragma unroll
         for (int j = 0; j < BP; ++j)
             xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_off[j], soff, 0);
-        // advance to the next tile: segment fastest, then kw, then kh
-        if (++cs == p.cseg) {
-            cs = 0;
-            if (++kw == p.KW) {
-                kw = 0;
-                ++kh;
-            }
-        }
     };
 
-    auto store_tile = [&](int buf, const u32x4 (&xa)[AP], const u32x4 (&xb)[BP]) {
-        float *As = lds + buf * STAGE;
-        float *Bs = As + BM * ROW_FLOATS;
+    // LDS addresses are per-thread constants plus compile-time offsets (buffer, row block):
+    // (row >> 1) & 7 of rows r0 + 32j is that of r0, so one base serves every staged row
+    float *const stage_base = lds + r0 * ROW_FLOATS + (c ^ ((r0 >> 1) & 7)) * 4;
+    auto store_tile = [&](auto buf_c, const u32x4 (&xa)[AP], const u32x4 (&xb)[BP]) {
+        const int buf = buf_c;  // compile-time (Buf0 / Buf1) or a run-time 0 / 1
 #pragma unroll
-        for (int j = 0; j < AP; ++j) {
-            const int row = r0 + 32 * j;
-            const int pc = c ^ ((row >> 1) & 7);
-            *reinterpret_cast<u32x4 *>(As + row * ROW_FLOATS + pc * 4) = xa[j];
-        }
+        for (int j = 0; j < AP; ++j)
+            *reinterpret_cast<u32x4 *>(stage_base + buf * STAGE + 32 * j * ROW_FLOATS) = xa[j];
 #pragma unroll
-        for (int j = 0; j < BP; ++j) {
-            const int row = r0 + 32 * j;
-            const int pc = c ^ ((row >> 1) & 7);
-            *reinterpret_cast<u32x4 *>(Bs + row * ROW_FLOATS + pc * 4) = xb[j];
-        }
+        for (int j = 0; j < BP; ++j)
+            *reinterpret_cast<u32x4 *>(stage_base + buf * STAGE + (BM + 32 * j) * ROW_FLOATS) = xb[j];
     };
+    using Buf0 = std::integral_constant<int, 0>;
+    using Buf1 = std::integral_constant<int, 1>;
 
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -326,27 +321,30 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
 
     f32x16 acc[MI][NI];
 
-    auto compute_tile = [&](int buf) {
-        const float *As = lds + buf * STAGE + (wr * (BM / 2) + li) * ROW_FLOATS;
-        const float *Bs = lds + buf * STAGE + BM * ROW_FLOATS + (wc * (BN / 2) + li) * ROW_FLOATS;
-        // Issue priority: LOW while this wave streams MFMAs, HIGH for everything else.  A wave
-        // in its prologue / staging / epilogue shares the SIMD with another block's MFMA
-        // stream; at equal priority it got about one instruction per 64-cycle MFMA (stamps:
-        // 8 us for a 300-instruction epilogue), which kept blocks resident 2-3x longer than
-        // their work and starved the matrix pipe of ready blocks.
+    // fragment addresses: lane (li, lh) reads chunk 2*ks+lh of its rows: fp32 -> k =
+    // 8ks+4lh+{0..3}, bf16 -> k = 16ks+8lh+{0..7} (exactly the operand map of the 32x32x16
+    // MFMA).  Four per-thread bases (one per k-step), everything else is an immediate.
+    const float *frag_a[4], *frag_b[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int pc = ((2 * ks + lh) ^ sw) * 4;
+        frag_a[ks] = lds + (wr * (BM / 2) + li) * ROW_FLOATS + pc;
+        frag_b[ks] = lds + BM * ROW_FLOATS + (wc * (BN / 2) + li) * ROW_FLOATS + pc;
+    }
+    auto compute_tile = [&](auto buf_c) {
+        const int buf = buf_c;  // compile-time (Buf0 / Buf1) or a run-time 0 / 1
+        // Issue priority: LOW while this wave streams MFMAs, HIGH for everything else (a wave
+        // in its prologue / staging / epilogue shares the SIMD with another block's MFMAs).
         __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            // lane (li, lh) reads chunk 2*ks+lh of its rows: fp32 -> k = 8ks+4lh+{0..3},
-            // bf16 -> k = 16ks+8lh+{0..7} (exactly the operand map of the 32x32x16 MFMA)
-            const int pc = ((2 * ks + lh) ^ sw) * 4;
             u32x4 a[MI], b[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                a[mi] = *reinterpret_cast<const u32x4 *>(As + mi * 32 * ROW_FLOATS + pc);
+                a[mi] = *reinterpret_cast<const u32x4 *>(frag_a[ks] + buf * STAGE + mi * 32 * ROW_FLOATS);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
-                b[ni] = *reinterpret_cast<const u32x4 *>(Bs + ni * 32 * ROW_FLOATS + pc);
+                b[ni] = *reinterpret_cast<const u32x4 *>(frag_b[ks] + buf * STAGE + ni * 32 * ROW_FLOATS);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -425,25 +423,55 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
-        store_tile(0, ra, rb);
+        store_tile(Buf0{}, ra, rb);
         __syncthreads();
         if (vtile == blockIdx.x) stamp(p.stamps, 1);  // first operands landed and staged
 
         const unsigned vnext = vtile + gridDim.x;
         const bool has_next = vnext < total_tiles;
         int m0n = 0, n0n = 0;
-        for (int kt = 0; kt < p.nk; ++kt) {
-            const bool more = kt + 1 < p.nk;
-            if (more) load_tile(kt + 1, ra, rb);
-            compute_tile(kt & 1);
-            if (more) store_tile((kt + 1) & 1, ra, rb);
+        if constexpr (sizeof(T) == 4) {
+            // fp32 (MFMA-bound): two K tiles per trip so that the LDS buffer of every access is
+            // a compile-time offset -- no vector ALU work at all between the MFMAs.  Inside the
+            // loop both loads are unconditional (no phi copies of the staging registers); the
+            // last one or two tiles are peeled.
+            int kt = 0;
+            while (kt + 2 < p.nk) {
+                load_tile(kt + 1, ra, rb);
+                compute_tile(Buf0{});
+                store_tile(Buf1{}, ra, rb);
+                __syncthreads();
+                load_tile(kt + 2, ra, rb);
+                compute_tile(Buf1{});
+                store_tile(Buf0{}, ra, rb);
+                __syncthreads();
+                kt += 2;
+            }
+            if (kt + 1 < p.nk) {  // two tiles left: kt in buffer 0, kt + 1 still to fetch
+                load_tile(kt + 1, ra, rb);
+                compute_tile(Buf0{});
+                store_tile(Buf1{}, ra, rb);
+                __syncthreads();
+                compute_tile(Buf1{});
+            } else {  // one tile left, in buffer 0
+                compute_tile(Buf0{});
+            }
             __syncthreads();
+        } else {
+            // bf16 (latency-bound): the compact loop keeps the register count, and with it the
+            // number of resident blocks, where the unrolled form costs 10 % throughput
+            for (int kt = 0; kt < p.nk; ++kt) {
+                const bool more = kt + 1 < p.nk;
+                if (more) load_tile(kt + 1, ra, rb);
+                compute_tile(kt & 1);
+                if (more) store_tile((kt + 1) & 1, ra, rb);
+                __syncthreads();
+            }
         }
         // next tile of this block: its first K tile starts travelling before the epilogue
         if (has_next) {
             tile_origin(vnext, m0n, n0n);
             setup_rows(m0n, n0n);
-            kh = kw = cs = 0;
             load_tile(0, ra, rb);
         }
 
@@ -693,6 +721,8 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     p.HoWo = p.Ho * p.Wo;
     fast_div((unsigned)p.HoWo, &p.mul_hw, &p.shr_hw);
     fast_div((unsigned)p.Wo, &p.mul_w, &p.shr_w);
+    fast_div((unsigned)p.cseg, &p.mul_cs, &p.shr_cs);
+    fast_div((unsigned)p.KW, &p.mul_kw, &p.shr_kw);
     p.stamps = (unsigned long long *)ctx->debug_stamps;
     p.in_bytes = (int)(B * H * W * (uint64_t)p.Cs * es);
     p.w_bytes = (int)(Cout * (uint64_t)p.Ktot * es);
