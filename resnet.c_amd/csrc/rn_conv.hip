@@ -4,44 +4,56 @@
 // thread per output element, K = Cin*k*k global-load pairs each;
 // linearForwardKernel (ops.cu:110-128) the same for x.W^T + b.
 //
-// Here both are ONE implicit-GEMM kernel on the fp32 matrix cores of gfx950:
+// Here both are ONE implicit-GEMM kernel on the matrix cores of gfx950:
 //
 //     out[m][n] = sum_k A[m][k] * Wp[n][k]        m = (b, oh, ow), n = out channel
 //
 //  * activations are NHWC, so for a fixed kernel tap (kh, kw) the K slice of a row
-//    of A is a contiguous run of input channels: the K loop walks (kh, kw, 32-channel
-//    segment) and every A row of a K tile is one 128-byte read, or zeros when the
-//    tap falls into the padding (the reference skips those taps, ops.cu:35-37);
+//    of A is a contiguous run of input channels: the K loop walks (kh, kw, 128-byte
+//    channel segment) and every A row of a K tile is one 128-byte read, or zeros
+//    when the tap falls into the padding (the reference skips those taps,
+//    ops.cu:35-37);
 //  * weights are pre-packed K-major [Cout][kh][kw][Cin] so B rows are 128-byte reads;
-//  * the 3-channel stem reads a [B,H,W,4] zero-padded image: one K segment is then
-//    8 consecutive pixels x 4 channels of one input row (kw slot 7 and channel 3
-//    carry zero weights), which turns the 7x7 stem into 7 K tiles of the same kernel;
-//  * v_mfma_f32_32x32x2_f32: exact fp32 products and sums (bitwise an fmaf chain in
-//    k order), 256 FLOP/clk/CU = the 157 TFLOP/s fp32 roof of the chip;
+//  * the 3-channel stem reads a zero-padded 4-channel image: one K segment is then
+//    8 (fp32) or 16 (bf16) consecutive pixels of one input row (unused kw slots and
+//    channel 3 carry zero weights), which turns the 7x7 stem into 7 K tiles;
+//  * fp32: v_mfma_f32_32x32x2_f32 -- exact fp32 products and sums (bitwise an fmaf
+//    chain in k order), 256 FLOP/clk/CU = the 157 TFLOP/s fp32 roof of the chip;
+//    bf16 storage: v_mfma_f32_32x32x16_bf16 on the same 128-byte LDS rows;
 //  * 256 threads = 4 waves as 2x2, each wave owns (BM/2)x(BN/2) as 32x32 MFMA tiles;
-//    operands staged through LDS as [rows][32 floats] images whose 16-byte chunks
-//    are XOR-swizzled with (row>>1)&7, which makes both the ds_write_b128 of the
-//    staging pass and the ds_read_b128 of the fragment reads bank-conflict free;
-//  * one ds_read_b128 feeds four MFMAs: lane (i, h) reads 4 consecutive k of row i
-//    at chunk 2*ks+h, MFMA j of the group consumes element j, i.e. k = 8ks+j from
-//    the low half-wave and 8ks+4+j from the high one -- A and B use the same map,
-//    so the sum is over the same k set in a fixed order;
+//    operands staged through LDS as [rows][128 B] images whose 16-byte chunks are
+//    XOR-swizzled with (row>>1)&7, which makes both the ds_write_b128 of the staging
+//    pass and the ds_read_b128 of the fragment reads bank-conflict free;
+//  * one ds_read_b128 feeds four fp32 MFMAs (one bf16 MFMA): lane (i, h) reads chunk
+//    2*ks+h of row i; A and B use the same map, so every output element sums the same
+//    k set in the same fixed order whatever the tile shape (all tile candidates are
+//    bit-identical);
 //  * register-staged double buffering: global loads of tile t+1 are issued before
 //    the MFMAs of tile t and written to the other LDS buffer after them; one
 //    barrier per K tile;
-//  * XCD-aware block order: each of the 8 XCDs gets a contiguous range of tiles with
-//    the N tiles of one M panel adjacent, so the A panel is re-read from that
-//    XCD's L2, not from HBM;
-//  * fused epilogue on the accumulator registers: per-channel scale/shift (folded
-//    batch-norm or fc bias), residual add, ReLU.
+//  * no vector-ALU work between the MFMAs (it competes with fp32 MFMA issue): operand
+//    offsets are per-tap constants, the K position is scalar arithmetic, K segments go
+//    through the buffer load's scalar offset, LDS addresses are per-thread constants
+//    plus immediates (fp32: two K tiles per loop trip);
+//  * every load and store is issued unconditionally through range-checked buffer
+//    descriptors (padding, ragged rows, absent residual = out-of-range offset): a
+//    conditional memory operation between a prefetch and its use makes hipcc wait
+//    vmcnt(0), which had serialised the row stores of the epilogue;
+//  * XCD-aware tile order: each of the 8 XCDs gets a contiguous range of tiles with
+//    the N tiles of one M panel adjacent, so the A panel is re-read from that XCD's
+//    L2; a block either owns one tile or (resident grid) walks tiles and fetches the
+//    next tile's first operands during its epilogue;
+//  * fused epilogue through LDS -> row-contiguous 16-byte stores: per-channel
+//    scale/shift (folded batch-norm or fc bias), residual add (tile prefetched), ReLU.
 //
-// Roofline: MFMA-bound for K*N/(K+N) above ~80 (every ResNet shape except the
-// 56x56 convs with 64 channels on one side, which are HBM-bound).  Algorithmic
-// bytes: 4*(M*K_in + N*K + M*N), flops 2*M*N*K.
+// Roofline: MFMA-bound for K*N/(K+N) above ~80 in fp32 (every ResNet shape except the
+// 56x56 convs with 64 channels on one side, which are HBM-bound); HBM/latency-bound
+// everywhere with bf16 storage.  Algorithmic bytes: es*(M*K_in + N*K + M*N) (+ es*M*N
+// with a residual), flops 2*M*N*K.
 //
 // Shapes the GEMM cannot take (Cin not a multiple of 32 and not the small-Cin stem
-// form) run a direct kernel that keeps the reference's exact summation order
-// ic -> kh -> kw.
+// form, or tensors of 2 GiB and more) run a direct fp32 kernel that keeps the
+// reference's exact summation order ic -> kh -> kw.
 #include <type_traits>
 
 #include "rn_internal.h"
