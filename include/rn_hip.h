@@ -251,6 +251,26 @@ RN_API int rn_model_profile_get(const rn_model *m, uint64_t index, const char **
                                 double *bytes);
 RN_API uint64_t rn_model_activation_bytes(const rn_model *m);
 
+/* ---- host pipeline: overlapped upload / forward / download --------------------------
+ * What main() of the reference does once (H2D of the image, forward, D2H of the logits:
+ * main.cu:236-240) as a stream of batches: two slots; the upload of batch i+1 (pinned
+ * staging -> device, on a copy stream) runs beside the forward of batch i.  submit() blocks
+ * only when both slots are busy; collect() returns the logits of the oldest batch. */
+typedef struct rn_pipeline rn_pipeline;
+RN_API int rn_pipeline_create(rn_model *m, rn_pipeline **out, uint64_t B, int mode);
+RN_API int rn_pipeline_destroy(rn_pipeline *p);
+/* The pinned staging buffer (B*3*224*224 floats) the next submit will upload from: a decoder
+ * that writes its output there saves the host-side copy.  RN_ERR_INVALID when both slots are
+ * busy. */
+RN_API int rn_pipeline_input_buffer(rn_pipeline *p, float **host_staging);
+/* host_input_nchw: B*3*224*224 floats in any host memory (copied into the staging buffer), or
+ * NULL / the pointer rn_pipeline_input_buffer returned when the staging buffer is already
+ * filled. */
+RN_API int rn_pipeline_submit(rn_pipeline *p, const float *host_input_nchw);
+/* host_logits: B*1000 floats.  RN_ERR_INVALID when nothing is in flight. */
+RN_API int rn_pipeline_collect(rn_pipeline *p, float *host_logits);
+RN_API uint64_t rn_pipeline_in_flight(const rn_pipeline *p);
+
 #ifdef __cplusplus
 }
 #endif

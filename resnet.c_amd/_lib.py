@@ -96,6 +96,12 @@ SIGNATURES = {
     "rn_model_profile_get": (c_int, [c_void_p, u64, POINTER(c_char_p), POINTER(c_char_p),
                                      POINTER(c_float), POINTER(c_double), POINTER(c_double)]),
     "rn_model_activation_bytes": (u64, [c_void_p]),
+    "rn_pipeline_create": (c_int, [c_void_p, POINTER(c_void_p), u64, c_int]),
+    "rn_pipeline_destroy": (c_int, [c_void_p]),
+    "rn_pipeline_input_buffer": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "rn_pipeline_submit": (c_int, [c_void_p, c_void_p]),
+    "rn_pipeline_collect": (c_int, [c_void_p, c_void_p]),
+    "rn_pipeline_in_flight": (u64, [c_void_p]),
 }
 
 _lib = None

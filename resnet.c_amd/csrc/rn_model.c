@@ -402,6 +402,9 @@ static int ensure_acts(rn_model *m, uint64_t B)
 
 uint64_t rn_model_activation_bytes(const rn_model *m) { return m ? m->act_bytes : 0; }
 
+/* library-internal: the pipeline (rn_pipeline.hip) queues on the model's stream */
+rn_ctx *rn_model_context(rn_model *m) { return m ? m->ctx : NULL; }
+
 /* ---- profiling --------------------------------------------------------- */
 static int prof_begin(rn_model *m, const char *op, const char *layer, double flops, double bytes)
 {

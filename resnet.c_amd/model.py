@@ -292,3 +292,64 @@ class NativeModel:
             self.close()
         except Exception:
             pass
+
+
+class Pipeline:
+    """Stream of host batches through a NativeModel with the upload of the next batch
+    overlapped with the forward of the current one (rn_pipeline_*, two slots)."""
+
+    def __init__(self, model: NativeModel, batch: int, fused: bool = True):
+        self.model, self.batch = model, batch
+        h = ctypes.c_void_p()
+        L.check(L.lib().rn_pipeline_create(model.handle, ctypes.byref(h), batch,
+                                           L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS),
+                "rn_pipeline_create", model.ctx.handle)
+        self.handle = h
+
+    def input_buffer(self) -> np.ndarray:
+        """The pinned staging buffer of the next slot as a [B,3,224,224] array: fill it in
+        place, then submit() without an argument."""
+        ptr = ctypes.c_void_p()
+        L.check(L.lib().rn_pipeline_input_buffer(self.handle, ctypes.byref(ptr)),
+                "rn_pipeline_input_buffer", self.model.ctx.handle)
+        n = self.batch * 3 * 224 * 224
+        buf = (ctypes.c_float * n).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.float32).reshape(self.batch, 3, 224, 224)
+
+    def submit(self, x: np.ndarray | None = None) -> None:
+        ptr = None
+        if x is not None:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            assert x.shape == (self.batch, 3, 224, 224)
+            ptr = x.ctypes.data
+        L.check(L.lib().rn_pipeline_submit(self.handle, ptr), "rn_pipeline_submit",
+                self.model.ctx.handle)
+
+    def collect(self) -> np.ndarray:
+        out = np.empty((self.batch, 1000), dtype=np.float32)
+        L.check(L.lib().rn_pipeline_collect(self.handle, out.ctypes.data), "rn_pipeline_collect",
+                self.model.ctx.handle)
+        return out
+
+    def in_flight(self) -> int:
+        return int(L.lib().rn_pipeline_in_flight(self.handle))
+
+    def run(self, batches):
+        """Yield logits for an iterable of host batches, keeping two in flight."""
+        for x in batches:
+            if self.in_flight() == 2:
+                yield self.collect()
+            self.submit(x)
+        while self.in_flight():
+            yield self.collect()
+
+    def close(self) -> None:
+        if self.handle:
+            L.lib().rn_pipeline_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
