@@ -94,8 +94,8 @@ RN_API int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on);
  * candidate i (all candidates give bit-identical results; used by rn_model_tune). */
 RN_API int rn_conv_tile_candidates(void);
 RN_API int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate);
-/* Diagnostics: device buffer of 8 x uint64 per block that the contraction kernel fills with
- * wall-clock stamps of its phases (tools/conv_stamps.py); NULL (default) = off. */
+/* Diagnostics: device buffer of 16 x uint64 per block that the contraction kernel fills with
+ * wall-clock and shader-clock stamps of its phases (tools/conv_stamps.py); NULL (default) = off. */
 RN_API int rn_ctx_set_debug_stamps(rn_ctx *ctx, void *dev_buffer);
 RN_API void *rn_ctx_stream(rn_ctx *ctx);
 RN_API int rn_ctx_device(const rn_ctx *ctx);
@@ -250,6 +250,20 @@ RN_API int rn_model_profile_get(const rn_model *m, uint64_t index, const char **
                                 const char **layer_name, float *ms, double *flops,
                                 double *bytes);
 RN_API uint64_t rn_model_activation_bytes(const rn_model *m);
+
+/* ---- captured forward ---------------------------------------------------------------
+ * The forward of one (input, B, logits, mode) as a hipGraph: ~57 launches (RN-50, fused) replayed
+ * by one call.  Worth it at small B, where the launches' host cost is comparable to their GPU
+ * time; at B=256 the GPU is the bound either way.  Capture runs one eager forward first (arenas
+ * and scratch are allocated outside the capture) and bakes in the tile choice of that moment
+ * (call rn_model_tune before).  Needs profiling and sync_each_op off (RN_ERR_INVALID otherwise).
+ * The buffers must stay valid while the graph lives. */
+typedef struct rn_graph rn_graph;
+RN_API int rn_model_capture(rn_model *m, const float *input_nchw, uint64_t B, float *logits,
+                            int mode, rn_graph **out);
+RN_API int rn_graph_launch(rn_graph *g); /* asynchronous, on the context's stream */
+RN_API int rn_graph_destroy(rn_graph *g);
+RN_API uint64_t rn_graph_node_count(const rn_graph *g);
 
 /* ---- host pipeline: overlapped upload / forward / download --------------------------
  * What main() of the reference does once (H2D of the image, forward, D2H of the logits:

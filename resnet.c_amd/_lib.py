@@ -96,6 +96,10 @@ SIGNATURES = {
     "rn_model_profile_get": (c_int, [c_void_p, u64, POINTER(c_char_p), POINTER(c_char_p),
                                      POINTER(c_float), POINTER(c_double), POINTER(c_double)]),
     "rn_model_activation_bytes": (u64, [c_void_p]),
+    "rn_model_capture": (c_int, [c_void_p, fptr, u64, fptr, c_int, POINTER(c_void_p)]),
+    "rn_graph_launch": (c_int, [c_void_p]),
+    "rn_graph_destroy": (c_int, [c_void_p]),
+    "rn_graph_node_count": (u64, [c_void_p]),
     "rn_pipeline_create": (c_int, [c_void_p, POINTER(c_void_p), u64, c_int]),
     "rn_pipeline_destroy": (c_int, [c_void_p]),
     "rn_pipeline_input_buffer": (c_int, [c_void_p, POINTER(c_void_p)]),

@@ -89,7 +89,7 @@ struct GemmParams {
     unsigned mul_hw, shr_hw, mul_w, shr_w;  // n / d == umulhi(n, mul) >> shr for n < 2^31
     unsigned mul_cs, shr_cs, mul_kw, shr_kw;  // K tile -> (tap, segment), tap -> (kh, kw)
     int in_bytes, w_bytes, out_bytes;
-    // diagnostic only (tools/conv_stamps.py): 8 wall-clock stamps per block, or null
+    // diagnostic only (tools/conv_stamps.py): 16 stamp slots per block, or null
     unsigned long long *stamps;
 };
 
@@ -114,7 +114,12 @@ constexpr int ROW_FLOATS = 32;
 // buffer was attached to the context.  Nothing else reads that buffer.
 __device__ __forceinline__ void stamp(unsigned long long *buf, int slot)
 {
-    if (buf && threadIdx.x == 0) buf[(size_t)blockIdx.x * 8 + slot] = wall_clock64();
+    if (buf && threadIdx.x == 0) buf[(size_t)blockIdx.x * 16 + slot] = wall_clock64();
+}
+// ... and of the shader clock (s_memtime), to read the clock the chip holds inside the K loop
+__device__ __forceinline__ void stamp_cycles(unsigned long long *buf, int slot)
+{
+    if (buf && threadIdx.x == 0) buf[(size_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memtime();
 }
   // LDS row = 128 bytes, addressed as 32 dwords
 
@@ -437,7 +442,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
         store_tile(Buf0{}, ra, rb);
         __syncthreads();
-        if (vtile == blockIdx.x) stamp(p.stamps, 1);  // first operands landed and staged
+        if (vtile == blockIdx.x) {
+            stamp(p.stamps, 1);  // first operands landed and staged
+            stamp_cycles(p.stamps, 8);
+        }
 
         const unsigned vnext = vtile + gridDim.x;
         const bool has_next = vnext < total_tiles;
@@ -491,7 +499,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         // traffic is row-contiguous 16-byte accesses: C/D map of the 32x32 MFMA is
         // col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); a ds_write_b32 of one register
         // puts 32 consecutive columns of two rows, conflict-free.
-        if (vtile == blockIdx.x) stamp(p.stamps, 2);  // K loop done
+        if (vtile == blockIdx.x) {
+            stamp_cycles(p.stamps, 9);
+            stamp(p.stamps, 2);  // K loop done
+        }
         float *Cs = lds;  // [BM][BN] fp32
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)

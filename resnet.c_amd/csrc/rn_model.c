@@ -404,6 +404,7 @@ uint64_t rn_model_activation_bytes(const rn_model *m) { return m ? m->act_bytes 
 
 /* library-internal: the pipeline (rn_pipeline.hip) queues on the model's stream */
 rn_ctx *rn_model_context(rn_model *m) { return m ? m->ctx : NULL; }
+int rn_model_profiling_enabled(const rn_model *m) { return m ? m->profiling : 0; }
 
 /* ---- profiling --------------------------------------------------------- */
 static int prof_begin(rn_model *m, const char *op, const char *layer, double flops, double bytes)

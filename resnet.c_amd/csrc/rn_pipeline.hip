@@ -7,6 +7,13 @@
 
 #include "rn_internal.h"
 
+struct rn_graph {
+    rn_ctx *ctx;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    size_t nodes;
+};
+
 struct rn_pipeline_slot {
     float *h_in, *h_out;  // pinned
     float *d_in, *d_out;
@@ -28,6 +35,64 @@ extern "C" {
 
 // the model keeps its context private; the pipeline needs it for the compute stream
 rn_ctx *rn_model_context(rn_model *m);
+
+int rn_model_profiling_enabled(const rn_model *m);
+
+int rn_graph_destroy(rn_graph *g)
+{
+    if (!g) return RN_OK;
+    if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    free(g);
+    return RN_OK;
+}
+
+int rn_model_capture(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode,
+                     rn_graph **out)
+{
+    if (!m || !out) return RN_ERR_INVALID;
+    *out = nullptr;
+    rn_ctx *ctx = rn_model_context(m);
+    if (ctx->sync_each_op)
+        return rn_set_error(ctx, RN_ERR_INVALID, "rn_model_capture: sync_each_op must be off");
+    if (rn_model_profiling_enabled(m))
+        return rn_set_error(ctx, RN_ERR_INVALID, "rn_model_capture: profiling must be off");
+    // eager pass: validates the arguments, sizes the arenas and the scratch outside the capture
+    RN_TRY(rn_model_forward(m, input_nchw, B, logits, mode));
+    RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rn_graph *g = (rn_graph *)calloc(1, sizeof(rn_graph));
+    if (!g) return RN_ERR_NOMEM;
+    g->ctx = ctx;
+    hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        free(g);
+        return rn_check_hip(ctx, e, "hipStreamBeginCapture");
+    }
+    const int st = rn_model_forward(m, input_nchw, B, logits, mode);
+    e = hipStreamEndCapture(ctx->stream, &g->graph);  // always end the capture, even on error
+    if (st != RN_OK || e != hipSuccess) {
+        rn_graph_destroy(g);
+        return st != RN_OK ? st : rn_check_hip(ctx, e, "hipStreamEndCapture");
+    }
+    e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e == hipSuccess) e = hipGraphGetNodes(g->graph, nullptr, &g->nodes);
+    if (e != hipSuccess) {
+        rn_graph_destroy(g);
+        return rn_check_hip(ctx, e, "hipGraphInstantiate");
+    }
+    *out = g;
+    return RN_OK;
+}
+
+int rn_graph_launch(rn_graph *g)
+{
+    if (!g) return RN_ERR_INVALID;
+    RN_HIP_TRY(g->ctx, hipGraphLaunch(g->exec, g->ctx->stream));
+    return RN_OK;
+}
+
+uint64_t rn_graph_node_count(const rn_graph *g) { return g ? (uint64_t)g->nodes : 0; }
 
 int rn_pipeline_destroy(rn_pipeline *p)
 {

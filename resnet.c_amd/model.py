@@ -294,6 +294,35 @@ class NativeModel:
             pass
 
 
+class Graph:
+    """A captured forward (rn_model_capture): launch() replays it on the context's stream."""
+
+    def __init__(self, model: NativeModel, input_ptr, batch: int, logits_ptr, fused: bool = True):
+        self.model = model
+        h = ctypes.c_void_p()
+        L.check(L.lib().rn_model_capture(model.handle, input_ptr, batch, logits_ptr,
+                                         L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS,
+                                         ctypes.byref(h)), "rn_model_capture", model.ctx.handle)
+        self.handle = h
+
+    def launch(self) -> None:
+        L.check(L.lib().rn_graph_launch(self.handle), "rn_graph_launch", self.model.ctx.handle)
+
+    def node_count(self) -> int:
+        return int(L.lib().rn_graph_node_count(self.handle))
+
+    def close(self) -> None:
+        if self.handle:
+            L.lib().rn_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Pipeline:
     """Stream of host batches through a NativeModel with the upload of the next batch
     overlapped with the forward of the current one (rn_pipeline_*, two slots)."""

@@ -224,3 +224,31 @@ def test_resnet101_vs_oracle(finch):
             assert np.array_equal(got.argmax(1), cpu.argmax(1))
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_captured_forward_replays_bit_exact(model50, finch, fused):
+    """rn_model_capture: the forward as one hipGraph launch; a replay reads the buffers as they
+    are at launch time and gives the eager forward's bits."""
+    B = 2
+    x0 = R.weights.generate_input(B, seed=61)
+    x1 = R.weights.generate_input(B, seed=62)
+    x1[1] = finch[0]
+    want0, want1 = model50.forward(x0, fused=fused), model50.forward(x1, fused=fused)
+    xd = R.FloatTensor.from_numpy(x0, R.Device.GPU)
+    out = R.FloatTensor((B, 1000), R.Device.GPU)
+    g = R.Graph(model50, xd.data(), B, out.data(), fused=fused)
+    assert g.node_count() >= 50
+    lib, ctx = R._lib.lib(), model50.ctx
+    R._lib.check(lib.rn_memset(ctx.handle, out.data(), 0, B * 4000), "memset", ctx.handle)
+    g.launch(); ctx.sync()
+    assert np.array_equal(out.numpy(), want0)
+    R._lib.check(lib.rn_memcpy_h2d(ctx.handle, xd.data(), x1.ctypes.data, x1.nbytes), "h2d", ctx.handle)
+    g.launch(); g.launch(); ctx.sync()
+    assert np.array_equal(out.numpy(), want1)
+    g.close()
+    # capture refuses the modes that put host synchronisation or events inside the forward
+    model50.set_profiling(True)
+    with pytest.raises(R.RnError):
+        R.Graph(model50, xd.data(), B, out.data(), fused=fused)
+    model50.set_profiling(False)

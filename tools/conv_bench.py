@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--residual", action="store_true")
     ap.add_argument("--relu", action="store_true")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--cand", type=int, default=-1, help="time this candidate only")
     a = ap.parse_args()
     B, H, W, Cin, Cout, k, s, p = a.dims
     lib, ctx = L.lib(), R.get_ctx()
@@ -50,7 +51,7 @@ def main():
     flops = 2.0 * B * ho * wo * Cout * Cin * k * k
     bytes_ = es * (B * H * W * Cin + wn + B * ho * wo * Cout * (2 if a.residual else 1))
     names = ["auto", "128x128", "128x64", "64x128", "64x64", "P128x128", "P128x64", "P64x128", "P64x64"]
-    for cand in range(0, lib.rn_conv_tile_candidates() + 1):
+    for cand in (range(0, lib.rn_conv_tile_candidates() + 1) if a.cand < 0 else [a.cand]):
         lib.rn_ctx_set_conv_tile(ctx.handle, cand)
         def run():
             L.check(lib.rn_conv2d_nhwc_forward_dt(ctx.handle, dt, dt, x.ptr, out.ptr, w.ptr, k, s, p, ho, wo,

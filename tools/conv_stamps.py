@@ -16,6 +16,7 @@ ap.add_argument("dims", type=int, nargs=8)
 ap.add_argument("--cand", type=int, default=1)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--residual", action="store_true")
+ap.add_argument("--soak", type=float, default=1.5, help="seconds of back-to-back launches before the stamped one")
 a = ap.parse_args()
 B, H, W, Cin, Cout, k, s, p = a.dims
 lib, ctx = L.lib(), R.get_ctx()
@@ -34,18 +35,23 @@ out = _DeviceBuffer(ctx, B * ho * wo * Cout * es); res = buf(B * ho * wo * Cout)
 sc = R.FloatTensor.from_numpy(np.ones(Cout, np.float32), R.Device.GPU)
 ep = L.Epilogue(sc.data(), sc.data(), res.ptr if res else None, 1)
 nblk = 1 << 16
-st = _DeviceBuffer(ctx, nblk * 64)
+st = _DeviceBuffer(ctx, nblk * 128)
 lib.rn_ctx_set_conv_tile(ctx.handle, a.cand)
 def run():
     L.check(lib.rn_conv2d_nhwc_forward_dt(ctx.handle, dt, dt, x.ptr, out.ptr, w.ptr, k, s, p, ho, wo, B, Cin, Cout, H, W, ctypes.byref(ep)), "conv", ctx.handle)
 run(); run(); ctx.sync()
-lib.rn_memset(ctx.handle, st.ptr, 0, nblk * 64)
+import time
+t_end = time.time() + a.soak
+while time.time() < t_end:
+    for _ in range(50): run()
+    ctx.sync()
+lib.rn_memset(ctx.handle, st.ptr, 0, nblk * 128)
 lib.rn_ctx_set_debug_stamps(ctx.handle, st.ptr)
 run(); ctx.sync()
 lib.rn_ctx_set_debug_stamps(ctx.handle, None)
-raw = np.empty(nblk * 8, dtype=np.uint64)
+raw = np.empty(nblk * 16, dtype=np.uint64)
 lib.rn_memcpy_d2h(ctx.handle, raw.ctypes.data, st.ptr, raw.nbytes)
-full = raw.reshape(nblk, 8).astype(np.float64)
+full = raw.reshape(nblk, 16).astype(np.float64)
 t = full[:, :5]
 keep = t[:, 0] > 0
 full = full[keep]
@@ -64,3 +70,6 @@ if full[:, 5].max() > 0:
 if full[:, 7].max() > 0:
     print(f"  prologue: start -> set-up done              median {np.median(full[:,7]-full[:,0])/100:7.2f} us")
     print(f"  prologue: loads issued -> staged + barrier  median {np.median(full[:,1]-full[:,7])/100:7.2f} us")
+if full[:, 9].max() > 0:
+    ghz = (full[:, 9] - full[:, 8]) / np.maximum(full[:, 2] - full[:, 1], 1) * 0.1
+    print(f"  shader clock inside the K loop              median {np.median(ghz):7.3f} GHz   p10 {np.percentile(ghz,10):.3f}  p90 {np.percentile(ghz,90):.3f}")
