@@ -243,6 +243,10 @@ RN_API int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, fl
  * that batch size.  Results do not change (candidates are bit-identical), only speed. */
 RN_API int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode);
 /* per-op timing of the next forwards: 1 = bracket every op with events */
+/* Fused mode only: run conv3 + downsample of the first block of each stage as one contraction
+ * (rn_conv2d_nhwc_pair_forward_dt); on by default, off = downsample first, then conv3 with it
+ * as the residual.  Changing it invalidates the tuned tiles. */
+RN_API int rn_model_set_pair_fusion(rn_model *m, int on);
 RN_API int rn_model_set_profiling(rn_model *m, int on);
 /* after a profiled forward + rn_sync: number of ops, then one record per op */
 RN_API uint64_t rn_model_profile_count(const rn_model *m);
@@ -250,6 +254,34 @@ RN_API int rn_model_profile_get(const rn_model *m, uint64_t index, const char **
                                 const char **layer_name, float *ms, double *flops,
                                 double *bytes);
 RN_API uint64_t rn_model_activation_bytes(const rn_model *m);
+
+/* ---- fused pair: out = epilogue(conv(inp, W1) + conv1x1(inp2, W2)) ------------------
+ * One contraction whose K loop runs through both convolutions: the bottleneck's conv3 and the
+ * block's downsample convolution (main.cu:134-147) without writing and re-reading the
+ * downsample tensor.  One accumulator, so each branch's BatchNorm scale is folded into its
+ * weight rows when the pair is packed; the epilogue then carries only the summed shifts
+ * (scale = NULL), an optional residual and ReLU.  The second convolution is 1x1 / padding 0
+ * and must produce the same [B,h_out,w_out,Cout] shape.  Both channel counts must be
+ * multiples of 32 (fp32) / 64 (bf16): RN_ERR_UNSUPPORTED otherwise. */
+typedef struct rn_conv_second {
+    const void *inp;      /* [B,H,W,in_channels] NHWC, element type = dtype */
+    uint64_t in_channels, H, W, stride;
+} rn_conv_second;
+RN_API uint64_t rn_conv2d_packed_pair_weight_numel(uint64_t in_channels, uint64_t out_channels,
+                                                   uint64_t kernel_size, uint64_t in_channels2);
+/* rows [Cout][k*k*Cin + Cin2]; scale1 / scale2 (per out channel, nullable = 1) multiply the rows */
+RN_API int rn_conv2d_pack_weight_pair_dt(rn_ctx *ctx, int dtype, const float *w1_oihw,
+                                         const float *scale1, const float *w2_oihw,
+                                         const float *scale2, void *packed, uint64_t in_channels,
+                                         uint64_t out_channels, uint64_t kernel_size,
+                                         uint64_t in_channels2);
+RN_API int rn_conv2d_nhwc_pair_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void *inp,
+                                          void *out, const void *packed_pair_weight,
+                                          uint64_t kernel_size, uint64_t stride, uint64_t padding,
+                                          uint64_t h_out, uint64_t w_out, uint64_t B,
+                                          uint64_t in_channels, uint64_t out_channels, uint64_t H,
+                                          uint64_t W, const rn_conv_second *second,
+                                          const rn_epilogue *epilogue);
 
 /* ---- captured forward ---------------------------------------------------------------
  * The forward of one (input, B, logits, mode) as a hipGraph: ~57 launches (RN-50, fused) replayed

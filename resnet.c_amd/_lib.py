@@ -11,7 +11,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librn_hip.so")
+# RN_HIP_LIB: another build of the same library (A/B timing of kernel changes)
+LIB_PATH = os.environ.get("RN_HIP_LIB") or os.path.join(_HERE, "librn_hip.so")
 
 RN_OK = 0
 RN_ERR_INVALID, RN_ERR_HIP, RN_ERR_IO, RN_ERR_NOMEM, RN_ERR_UNSUPPORTED = 1, 2, 3, 4, 5
@@ -21,6 +22,11 @@ RN_DTYPE_F32, RN_DTYPE_BF16 = 0, 1
 
 u64 = c_uint64
 fptr = c_void_p  # device pointers travel as plain addresses
+
+
+class ConvSecond(ctypes.Structure):
+    _fields_ = [("inp", c_void_p), ("in_channels", c_uint64), ("H", c_uint64), ("W", c_uint64),
+                ("stride", c_uint64)]
 
 
 class Epilogue(ctypes.Structure):
@@ -80,6 +86,12 @@ SIGNATURES = {
     "rn_nchw_to_nhwc_pad_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 6),
     "rn_conv2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, c_int, fptr, fptr, fptr] + [u64] * 10
                                   + [POINTER(Epilogue)]),
+    "rn_conv2d_packed_pair_weight_numel": (u64, [u64, u64, u64, u64]),
+    "rn_conv2d_pack_weight_pair_dt": (c_int, [c_void_p, c_int, fptr, fptr, fptr, fptr, fptr]
+                                      + [u64] * 4),
+    "rn_conv2d_nhwc_pair_forward_dt": (c_int, [c_void_p, c_int, c_int, fptr, fptr, fptr] + [u64] * 10
+                                       + [POINTER(ConvSecond), POINTER(Epilogue)]),
+    "rn_model_set_pair_fusion": (c_int, [c_void_p, c_int]),
     "rn_maxpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),
     "rn_avgpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),
     "rn_model_create": (c_int, [c_void_p, POINTER(c_void_p), c_int]),

@@ -89,6 +89,10 @@ struct GemmParams {
     unsigned mul_hw, shr_hw, mul_w, shr_w;  // n / d == umulhi(n, mul) >> shr for n < 2^31
     unsigned mul_cs, shr_cs, mul_kw, shr_kw;  // K tile -> (tap, segment), tap -> (kh, kw)
     int in_bytes, w_bytes, out_bytes;
+    // fused pair (DUAL kernels only): K tiles nk1.. come from a second NHWC tensor through a
+    // 1x1 / padding-0 convolution of the same output geometry (the downsample branch)
+    const void *in2;
+    int in2_bytes, H2, W2, Cs2, stride2, nk1;
     // diagnostic only (tools/conv_stamps.py): 16 stamp slots per block, or null
     unsigned long long *stamps;
 };
@@ -206,8 +210,9 @@ struct OutVec<bf16_t> {
 };
 
 // T: element type of activations and weights; TO: element type of the output (and residual)
-template <typename T, typename TO, int BM, int BN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
+// DUAL: the K loop continues through a second (input, weight-row tail) pair, see GemmParams
+template <typename T, typename TO, int BM, int BN, bool DUAL = false>
+__global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 ? 3 : 2)) void conv_gemm_kernel(const GemmParams p)
 {
     constexpr int CH = Elem<T>::CH, ES = (int)sizeof(T);
     constexpr int AP = BM / 32;  // A rows staged per thread
@@ -246,12 +251,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void *>(DUAL ? p.in2 : p.in), 0, DUAL ? p.in2_bytes : 0, 0x00020000);
     constexpr int kOob = (int)0x80000000;  // >= num_records for every tensor we accept
 
     // per staged A row: byte offset of tap (0,0) chunk c, and which taps are in bounds:
     // bit kh of the low half = row ih0+kh inside [0,H), bit kw of the high half = column;
     // per staged B row: constant per-thread offset (the K tile goes into the scalar offset)
     int a_off[AP], a_mask[AP], b_off[BP];
+    int a_off2[DUAL ? AP : 1];  // second source: byte offset of chunk c of the row's pixel
     auto setup_rows = [&](int m0_, int n0_) {
 #pragma unroll
         for (int j = 0; j < AP; ++j) {
@@ -271,9 +279,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
                 int cm = chi > clo ? ((1 << chi) - 1) & ~((1 << clo) - 1) : 0;
                 if (p.chunk_dw && c >= p.c4_chunks) cm = 0;  // chunk holds only zero-weight slots
                 a_mask[j] = rm | (cm << 16);
+                if constexpr (DUAL)
+                    a_off2[j] = (((b * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.Cs2 + c * CH) * ES;
             } else {
                 a_off[j] = 0;
                 a_mask[j] = 0;
+                if constexpr (DUAL) a_off2[j] = kOob;
             }
         }
 #pragma unroll
@@ -294,22 +305,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     // costs no vector ALU work at all (vector ALU work competes with the fp32 MFMA stream).
     auto load_tile = [&](int kt, u32x4 (&xa)[AP], u32x4 (&xb)[BP]) {
         const unsigned s_kt = (unsigned)__builtin_amdgcn_readfirstlane(kt);
-        const unsigned tap = p.cseg == 1 ? s_kt : (__umulhi(s_kt, p.mul_cs) >> p.shr_cs);
-        const int s_cs = (int)(s_kt - tap * (unsigned)p.cseg);
-        if (s_cs == 0) {
-            const unsigned ukh = p.KW == 1 ? tap : (__umulhi(tap, p.mul_kw) >> p.shr_kw);
-            const int s_kh = (int)ukh, s_kw = (int)(tap - ukh * (unsigned)p.KW);
-            const int toff = (s_kh * p.W + s_kw) * p.Cs * ES;
+        int s_cs;
+        __amdgpu_buffer_rsrc_t rs = rsrc_a;
+        if (DUAL && s_kt >= (unsigned)p.nk1) {
+            // second source: one tap, its segments follow the first source's K tiles
+            s_cs = (int)s_kt - p.nk1;
+            rs = rsrc_a2;
+            if (s_cs == 0) {
 #pragma unroll
-            for (int j = 0; j < AP; ++j) {
-                const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
-                a_cur[j] = ok ? a_off[j] + toff : kOob;
+                for (int j = 0; j < AP; ++j) a_cur[j] = a_off2[DUAL ? j : 0];
+            }
+        } else {
+            const unsigned tap = p.cseg == 1 ? s_kt : (__umulhi(s_kt, p.mul_cs) >> p.shr_cs);
+            s_cs = (int)(s_kt - tap * (unsigned)p.cseg);
+            if (s_cs == 0) {
+                const unsigned ukh = p.KW == 1 ? tap : (__umulhi(tap, p.mul_kw) >> p.shr_kw);
+                const int s_kh = (int)ukh, s_kw = (int)(tap - ukh * (unsigned)p.KW);
+                const int toff = (s_kh * p.W + s_kw) * p.Cs * ES;
+#pragma unroll
+                for (int j = 0; j < AP; ++j) {
+                    const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
+                    a_cur[j] = ok ? a_off[j] + toff : kOob;
+                }
             }
         }
         const int seg = s_cs * 128;
 #pragma unroll
         for (int j = 0; j < AP; ++j)
-            xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_cur[j], seg, 0);
+            xa[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, a_cur[j], seg, 0);
         const int soff = (int)s_kt * 128;
 #pragma unroll
         for (int j = 0; j < BP; ++j)
@@ -409,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const GemmParams p)
     // squeezed the fragment registers and exposed LDS latency inside the MFMA stream, so
     // large tiles fetch it at the start of the epilogue instead (the accumulators are dead
     // by then).
-    constexpr bool EARLY_RES = PASSES <= 8;
+    constexpr bool EARLY_RES = PASSES * (int)sizeof(T) <= 16;
 
     // residual rows and the channel constants of the CURRENT tile (m0, n0)
     auto prefetch_epilogue = [&]() {
@@ -668,13 +691,13 @@ void fast_div(unsigned d, unsigned *mul, unsigned *shr)
 }
 
 // Blocks of one instantiation that fit a CU at once (registers and LDS), asked once.
-template <typename T, typename TO, int BM, int BN>
+template <typename T, typename TO, int BM, int BN, bool DUAL>
 int resident_blocks_per_cu()
 {
     static int cached = 0;
     if (cached == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_kernel<T, TO, BM, BN>, 256,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_kernel<T, TO, BM, BN, DUAL>, 256,
                                                          0) != hipSuccess ||
             nb < 1)
             nb = 1;
@@ -683,28 +706,28 @@ int resident_blocks_per_cu()
     return cached;
 }
 
-template <typename T, typename TO, int BM, int BN>
+template <typename T, typename TO, int BM, int BN, bool DUAL>
 void launch_one(rn_ctx *ctx, GemmParams &p, bool persistent)
 {
     unsigned grid = p.total_tiles;
     if (persistent) {
-        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN>();
+        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN, DUAL>();
         if (grid > slots) grid = slots;
     }
-    conv_gemm_kernel<T, TO, BM, BN><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
+    conv_gemm_kernel<T, TO, BM, BN, DUAL><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
 }
 
-template <typename T, typename TO>
+template <typename T, typename TO, bool DUAL = false>
 void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent)
 {
     if (BMsel == 128 && BNsel == 128)
-        launch_one<T, TO, 128, 128>(ctx, p, persistent);
+        launch_one<T, TO, 128, 128, DUAL>(ctx, p, persistent);
     else if (BMsel == 128 && BNsel == 64)
-        launch_one<T, TO, 128, 64>(ctx, p, persistent);
+        launch_one<T, TO, 128, 64, DUAL>(ctx, p, persistent);
     else if (BMsel == 64 && BNsel == 128)
-        launch_one<T, TO, 64, 128>(ctx, p, persistent);
+        launch_one<T, TO, 64, 128, DUAL>(ctx, p, persistent);
     else
-        launch_one<T, TO, 64, 64>(ctx, p, persistent);
+        launch_one<T, TO, 64, 64, DUAL>(ctx, p, persistent);
 }
 
 // GEMM launch on NHWC data with packed weights.  Caller has checked eligibility.
@@ -712,7 +735,7 @@ void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persist
 int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, const void *packed,
                 uint64_t k, uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out,
                 uint64_t B, uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W,
-                const rn_epilogue *ep, const char *what)
+                const rn_epilogue *ep, const char *what, const rn_conv_second *second = nullptr)
 {
     const int es = dt_in == RN_DTYPE_BF16 ? 2 : 4;
     const int bke = 128 / es;
@@ -740,6 +763,18 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     p.c4_chunks = c4 ? (int)rn_ceil_div(k, p.chunk_dw) : 0;
     p.M = (int)(B * h_out * w_out);
     p.nk = p.KH * p.KW * p.cseg;
+    p.nk1 = p.nk;
+    p.in2 = nullptr;
+    p.in2_bytes = p.H2 = p.W2 = p.Cs2 = p.stride2 = 0;
+    if (second) {
+        p.in2 = second->inp;
+        p.H2 = (int)second->H;
+        p.W2 = (int)second->W;
+        p.Cs2 = (int)second->in_channels;
+        p.stride2 = (int)second->stride;
+        p.in2_bytes = (int)(B * second->H * second->W * second->in_channels * es);
+        p.nk += (int)(second->in_channels / bke);
+    }
     p.Ktot = p.nk * bke;
     p.HoWo = p.Ho * p.Wo;
     fast_div((unsigned)p.HoWo, &p.mul_hw, &p.shr_hw);
@@ -756,7 +791,7 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     // least (rounds * tile area / relative tile efficiency), i.e. the least padded,
     // best balanced cover of the 256 CUs.  rn_model_tune measures instead of guessing.
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    static const double cand_eff[4] = {1.00, 0.94, 0.94, 0.86};
+    static const double cand_eff[4] = {0.84, 0.95, 0.96, 1.00};  // measured, 3x3 and 1x1 at B=256
     int BMsel = 128, BNsel = 128;
     bool persistent;
     if (ctx->conv_tile >= 1 && ctx->conv_tile <= 8) {
@@ -785,7 +820,13 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     const uint64_t total = tiles_m * tiles_n;
     RN_REQUIRE(ctx, fits_i32(total), "too many tiles");
     p.total_tiles = (unsigned)total;
-    if (dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)
+    if (second && dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)
+        launch_tiles<float, float, true>(ctx, p, BMsel, BNsel, persistent);
+    else if (second && dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_BF16)
+        launch_tiles<bf16_t, bf16_t, true>(ctx, p, BMsel, BNsel, persistent);
+    else if (second)
+        return rn_set_error(ctx, RN_ERR_UNSUPPORTED, "%s: fused pair needs equal in/out dtype", what);
+    else if (dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)
         launch_tiles<float, float>(ctx, p, BMsel, BNsel, persistent);
     else if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_BF16)
         launch_tiles<bf16_t, bf16_t>(ctx, p, BMsel, BNsel, persistent);
@@ -972,6 +1013,53 @@ int rn_conv2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void 
     return launch_gemm(ctx, RN_DTYPE_BF16, out_dtype, inp, out, packed_weight, kernel_size, stride,
                        padding, h_out, w_out, B, in_channels, out_channels, H, W, epilogue,
                        "rn_conv2d_nhwc_forward_dt");
+}
+
+int rn_conv2d_nhwc_pair_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void *inp, void *out,
+                                   const void *packed_pair_weight, uint64_t kernel_size,
+                                   uint64_t stride, uint64_t padding, uint64_t h_out,
+                                   uint64_t w_out, uint64_t B, uint64_t in_channels,
+                                   uint64_t out_channels, uint64_t H, uint64_t W,
+                                   const rn_conv_second *second, const rn_epilogue *epilogue)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    RN_REQUIRE(ctx, second && second->inp, "second source missing");
+    RN_REQUIRE(ctx, dtype == RN_DTYPE_F32 || dtype == RN_DTYPE_BF16, "unknown dtype");
+    RN_REQUIRE(ctx, out_dtype == dtype, "the fused pair keeps one element type");
+    if (B * out_channels * h_out * w_out == 0) return RN_OK;
+    RN_REQUIRE(ctx, inp && out && packed_pair_weight && inp != out && second->inp != out,
+               "null or aliased tensor");
+    RN_REQUIRE(ctx, kernel_size >= 1 && kernel_size <= 15 && stride >= 1 && stride < (1u << 12) &&
+                        padding < (1u << 12) && second->stride >= 1 && second->stride < (1u << 12),
+               "kernel_size / stride / padding out of range");
+    const uint64_t seg = dtype == RN_DTYPE_BF16 ? 64 : 32;  // elements per 128-byte K tile
+    if (in_channels % seg != 0 || second->in_channels % seg != 0 || in_channels == 0 ||
+        second->in_channels == 0)
+        return rn_set_error(ctx, RN_ERR_UNSUPPORTED,
+                            "fused pair needs both channel counts to be multiples of %llu",
+                            (unsigned long long)seg);
+    RN_REQUIRE(ctx, rn_conv_output_size(H, kernel_size, stride, padding) == h_out &&
+                        rn_conv_output_size(W, kernel_size, stride, padding) == w_out,
+               "h_out / w_out do not match the first convolution");
+    RN_REQUIRE(ctx, rn_conv_output_size(second->H, 1, second->stride, 0) == h_out &&
+                        rn_conv_output_size(second->W, 1, second->stride, 0) == w_out,
+               "the second (1x1) convolution has a different output size");
+    const uint64_t ktot = kernel_size * kernel_size * in_channels + second->in_channels;
+    RN_REQUIRE(ctx, B * H * W * in_channels < (1ull << 29) &&
+                        B * second->H * second->W * second->in_channels < (1ull << 29) &&
+                        out_channels * ktot < (1ull << 29) &&
+                        B * h_out * w_out * out_channels < (1ull << 29),
+               "tensor too large");
+    RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out) |
+                      reinterpret_cast<uintptr_t>(packed_pair_weight) |
+                      reinterpret_cast<uintptr_t>(second->inp)) & 15) == 0,
+               "tensors must be 16-byte aligned");
+    if (epilogue && epilogue->residual)
+        RN_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(epilogue->residual) & 15) == 0,
+                   "misaligned residual");
+    return launch_gemm(ctx, dtype, out_dtype, inp, out, packed_pair_weight, kernel_size, stride,
+                       padding, h_out, w_out, B, in_channels, out_channels, H, W, epilogue,
+                       "rn_conv2d_nhwc_pair_forward_dt", second);
 }
 
 int rn_linear_forward(rn_ctx *ctx, const float *inp, float *out, const float *weight,

@@ -81,6 +81,31 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
     }
 }
 
+// fused pair: row oc = [kh][kw][Cin] of w1 * s1[oc], then [Cin2] of the 1x1 w2 * s2[oc]
+template <typename TP>
+__global__ __launch_bounds__(256) void pack_weight_pair_kernel(
+    const float *__restrict__ w1, const float *__restrict__ s1, const float *__restrict__ w2,
+    const float *__restrict__ s2, TP *__restrict__ packed, uint32_t Cin, uint32_t k, uint32_t Cin2,
+    uint64_t total)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    const uint32_t kk = k * k, K1 = kk * Cin, Kt = K1 + Cin2;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+        const uint32_t q = (uint32_t)(i % Kt);
+        const uint64_t oc = i / Kt;
+        float v;
+        if (q < K1) {
+            const uint32_t ic = q % Cin, tap = q / Cin;
+            v = w1[(oc * Cin + ic) * kk + tap];
+            if (s1) v *= s1[oc];
+        } else {
+            v = w2[oc * Cin2 + (q - K1)];
+            if (s2) v *= s2[oc];
+        }
+        packed[i] = (TP)v;
+    }
+}
+
 // small-Cin ("stem") panel: [Cout][kh][8 kw slots][4 channel slots], zero where kw >= k
 // or ic >= Cin, so one 32-float K segment = 8 consecutive pixels of a 4-channel image
 __global__ __launch_bounds__(256) void pack_weight_c4_kernel(const float *__restrict__ w,
@@ -195,6 +220,38 @@ int rn_conv2d_pack_weight(rn_ctx *ctx, const float *weight_oihw, float *packed,
             weight_oihw, packed, (uint32_t)in_channels, (uint32_t)kernel_size, total);
     }
     return rn_after_launch(ctx, "rn_conv2d_pack_weight");
+}
+
+uint64_t rn_conv2d_packed_pair_weight_numel(uint64_t in_channels, uint64_t out_channels,
+                                            uint64_t kernel_size, uint64_t in_channels2)
+{
+    return out_channels * (kernel_size * kernel_size * in_channels + in_channels2);
+}
+
+int rn_conv2d_pack_weight_pair_dt(rn_ctx *ctx, int dtype, const float *w1_oihw, const float *scale1,
+                                  const float *w2_oihw, const float *scale2, void *packed,
+                                  uint64_t in_channels, uint64_t out_channels, uint64_t kernel_size,
+                                  uint64_t in_channels2)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    RN_REQUIRE(ctx, dtype == RN_DTYPE_F32 || dtype == RN_DTYPE_BF16, "unknown dtype");
+    const uint64_t total =
+        rn_conv2d_packed_pair_weight_numel(in_channels, out_channels, kernel_size, in_channels2);
+    if (total == 0) return RN_OK;
+    RN_REQUIRE(ctx, w1_oihw && w2_oihw && packed, "null tensor");
+    RN_REQUIRE(ctx, in_channels >= 1 && in_channels2 >= 1 && kernel_size >= 1, "empty convolution");
+    RN_REQUIRE(ctx, kernel_size < (1u << 12) &&
+                        kernel_size * kernel_size * in_channels + in_channels2 < (1ull << 31),
+               "dimension too large");
+    if (dtype == RN_DTYPE_F32)
+        pack_weight_pair_kernel<float><<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
+            w1_oihw, scale1, w2_oihw, scale2, (float *)packed, (uint32_t)in_channels,
+            (uint32_t)kernel_size, (uint32_t)in_channels2, total);
+    else
+        pack_weight_pair_kernel<bf16_t><<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
+            w1_oihw, scale1, w2_oihw, scale2, (bf16_t *)packed, (uint32_t)in_channels,
+            (uint32_t)kernel_size, (uint32_t)in_channels2, total);
+    return rn_after_launch(ctx, "rn_conv2d_pack_weight_pair_dt");
 }
 
 uint64_t rn_conv2d_packed_weight_numel_dt(int dtype, uint64_t in_channels, uint64_t out_channels,

@@ -49,6 +49,12 @@ typedef struct {
 typedef struct {
     char name[RN_MAX_KEY];
     int conv1, conv2, conv3, ds; /* indices into convs; ds = -1 when absent */
+    /* blocks with a downsample branch: conv3 and downsample as one contraction
+     * (rn_conv2d_nhwc_pair_forward_dt): rows [Cout][K3 + Kd] with both batch-norm scales
+     * folded in, and the sum of the two shifts */
+    void *pair_packed;
+    float *pair_shift;
+    int pair_tile;
 } rn_block;
 
 typedef struct {
@@ -61,9 +67,10 @@ typedef struct {
 
 typedef struct {
     int conv;
-    const void *x;
+    int pair_block; /* >= 0: the fused conv3 + downsample call of that block (x2, H2, W2) */
+    const void *x, *x2;
     void *y;
-    uint64_t B, H, W, pad;
+    uint64_t B, H, W, pad, H2, W2;
     rn_epilogue ep;
     int has_ep;
 } rn_conv_call;
@@ -81,6 +88,7 @@ struct rn_model {
     int fc_w, fc_b;
     int finalized;
     int dtype;        /* storage type of activations and packed weights */
+    int pair_fusion;  /* fused mode: conv3 + downsample as one contraction (default on) */
     void *fc_packed;  /* fc.weight in the model dtype (bf16 models only) */
     /* activation arenas, sized for batch_cap images */
     uint64_t batch_cap;
@@ -149,6 +157,7 @@ int rn_model_create(rn_ctx *ctx, rn_model **out, int arch)
     else if (arch == 152) d = d152;
     else return RN_ERR_UNSUPPORTED;
     m = (rn_model *)calloc(1, sizeof(rn_model));
+    if (m) m->pair_fusion = 1;
     if (!m) return RN_ERR_NOMEM;
     m->ctx = ctx;
     m->arch = arch;
@@ -242,6 +251,12 @@ int rn_model_destroy(rn_model *m)
             rn_free(m->ctx, m->convs[c].shift);
         }
     }
+    if (m->blocks) {
+        for (c = 0; c < m->n_blocks; ++c) {
+            rn_free(m->ctx, m->blocks[c].pair_packed);
+            rn_free(m->ctx, m->blocks[c].pair_shift);
+        }
+    }
     rn_free(m->ctx, m->fc_packed);
     free_acts(m);
     free_prof(m);
@@ -317,6 +332,11 @@ int rn_model_set_dtype(rn_model *m, int dtype)
         m->convs[c].packed = NULL;
         m->convs[c].tile = 0;
     }
+    for (c = 0; c < m->n_blocks; ++c) {
+        rn_free(m->ctx, m->blocks[c].pair_packed);
+        m->blocks[c].pair_packed = NULL;
+        m->blocks[c].pair_tile = 0;
+    }
     rn_free(m->ctx, m->fc_packed);
     m->fc_packed = NULL;
     free_acts(m);
@@ -353,6 +373,29 @@ int rn_model_finalize(rn_model *m)
         st = rn_batchnorm2d_fold(m->ctx, m->params[cv->bn_w].dev, m->params[cv->bn_b].dev,
                                  m->params[cv->bn_m].dev, m->params[cv->bn_v].dev, cv->scale,
                                  cv->shift, cv->cout);
+        if (st != RN_OK) return st;
+    }
+    for (c = 0; c < m->n_blocks; ++c) {
+        rn_block *b = &m->blocks[c];
+        const rn_conv *c3, *cd;
+        if (b->ds < 0) continue;
+        c3 = &m->convs[b->conv3];
+        cd = &m->convs[b->ds];
+        if (!b->pair_packed) {
+            st = rn_malloc(m->ctx, &b->pair_packed,
+                           rn_conv2d_packed_pair_weight_numel(c3->cin, c3->cout, c3->k, cd->cin) *
+                               elem_size(m));
+            if (st != RN_OK) return st;
+        }
+        if (!b->pair_shift) {
+            st = rn_malloc(m->ctx, (void **)&b->pair_shift, c3->cout * sizeof(float));
+            if (st != RN_OK) return st;
+        }
+        st = rn_conv2d_pack_weight_pair_dt(m->ctx, m->dtype, m->params[c3->w].dev, c3->scale,
+                                           m->params[cd->w].dev, cd->scale, b->pair_packed, c3->cin,
+                                           c3->cout, c3->k, cd->cin);
+        if (st != RN_OK) return st;
+        st = rn_add_forward(m->ctx, c3->shift, cd->shift, b->pair_shift, c3->cout);
         if (st != RN_OK) return st;
     }
     if (m->dtype != RN_DTYPE_F32) {
@@ -404,6 +447,14 @@ uint64_t rn_model_activation_bytes(const rn_model *m) { return m ? m->act_bytes 
 
 /* library-internal: the pipeline (rn_pipeline.hip) queues on the model's stream */
 rn_ctx *rn_model_context(rn_model *m) { return m ? m->ctx : NULL; }
+int rn_model_set_pair_fusion(rn_model *m, int on)
+{
+    if (!m) return RN_ERR_INVALID;
+    m->pair_fusion = on ? 1 : 0;
+    m->tuned_B = 0; /* the set of launches changes */
+    return RN_OK;
+}
+
 int rn_model_profiling_enabled(const rn_model *m) { return m ? m->profiling : 0; }
 
 /* ---- profiling --------------------------------------------------------- */
@@ -494,6 +545,7 @@ static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint6
     if (m->recording) {
         rn_conv_call *c = &m->calls[m->n_calls++];
         c->conv = (int)(cv - m->convs);
+        c->pair_block = -1;
         c->x = x;
         c->y = y;
         c->B = B;
@@ -513,6 +565,42 @@ static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint6
         rn_ctx_set_conv_tile(m->ctx, 0);
         if (st != RN_OK) return st;
     }
+    return prof_end(m);
+}
+
+/* conv3 (input t, [B,H,W,c3->cin]) + downsample (input x, [B,H2,W2,cd->cin]) + shifts + ReLU */
+static int op_pair(rn_model *m, rn_block *b, const void *t, const void *x, void *y, uint64_t B,
+                   uint64_t H, uint64_t W, uint64_t H2, uint64_t W2)
+{
+    const rn_conv *c3 = &m->convs[b->conv3], *cd = &m->convs[b->ds];
+    const double M = (double)(B * H * W), K = (double)(c3->cin + cd->cin);
+    const double es = (double)elem_size(m);
+    const double bytes = es * ((double)(B * H * W * c3->cin) + (double)(B * H2 * W2 * cd->cin) +
+                               K * (double)c3->cout + M * (double)c3->cout);
+    char name[RN_MAX_KEY];
+    rn_conv_second second;
+    rn_epilogue ep;
+    int st;
+    second.inp = x; second.in_channels = cd->cin; second.H = H2; second.W = W2;
+    second.stride = cd->stride;
+    ep.scale = NULL; ep.shift = b->pair_shift; ep.residual = NULL; ep.relu = 1;
+    if (m->recording) {
+        rn_conv_call *c = &m->calls[m->n_calls++];
+        c->conv = b->conv3;
+        c->pair_block = (int)(b - m->blocks);
+        c->x = t; c->x2 = x; c->y = y;
+        c->B = B; c->H = H; c->W = W; c->pad = 0; c->H2 = H2; c->W2 = W2;
+        c->has_ep = 1;
+        c->ep = ep;
+    }
+    snprintf(name, sizeof(name), "%.*s+downsample", (int)(RN_MAX_KEY - 12), c3->name);
+    TRY(prof_begin(m, "conv2d+epilogue", name, 2.0 * M * (double)c3->cout * K, bytes));
+    rn_ctx_set_conv_tile(m->ctx, (m->tuned_B == B && m->tuned_mode == m->cur_mode) ? b->pair_tile : 0);
+    st = rn_conv2d_nhwc_pair_forward_dt(m->ctx, m->dtype, m->dtype, t, y, b->pair_packed, c3->k,
+                                        c3->stride, c3->pad, H, W, B, c3->cin, c3->cout, H, W,
+                                        &second, &ep);
+    rn_ctx_set_conv_tile(m->ctx, 0);
+    if (st != RN_OK) return st;
     return prof_end(m);
 }
 
@@ -540,7 +628,7 @@ static int op_add(rn_model *m, const char *layer, float *y, const float *shortcu
 }
 
 /* one bottleneck block (layerForward body, main.cu:131-164).  x -> y, both NHWC. */
-static int block_forward(rn_model *m, const rn_block *b, const float *x, float *y, uint64_t B,
+static int block_forward(rn_model *m, rn_block *b, const float *x, float *y, uint64_t B,
                          uint64_t *H, uint64_t *W, int mode)
 {
     const rn_conv *c1 = &m->convs[b->conv1], *c2 = &m->convs[b->conv2], *c3 = &m->convs[b->conv3];
@@ -550,7 +638,8 @@ static int block_forward(rn_model *m, const rn_block *b, const float *x, float *
     const float *shortcut = x;
     if (mode == RN_FWD_FUSED) {
         rn_epilogue ep;
-        if (b->ds >= 0) {
+        const int pair = b->ds >= 0 && m->pair_fusion;
+        if (b->ds >= 0 && !pair) {
             const rn_conv *cd = &m->convs[b->ds];
             ep.scale = cd->scale; ep.shift = cd->shift; ep.residual = NULL; ep.relu = 0;
             TRY(op_conv(m, cd, x, m->dsb, B, h, w, &ep, -1));
@@ -560,8 +649,13 @@ static int block_forward(rn_model *m, const rn_block *b, const float *x, float *
         TRY(op_conv(m, c1, x, m->t1, B, h, w, &ep, -1));
         ep.scale = c2->scale; ep.shift = c2->shift;
         TRY(op_conv(m, c2, m->t1, m->t2, B, h, w, &ep, -1));
-        ep.scale = c3->scale; ep.shift = c3->shift; ep.residual = shortcut;
-        TRY(op_conv(m, c3, m->t2, y, B, ho, wo, &ep, -1));
+        if (pair) {
+            /* the downsample tensor is never materialised: its K rows ride in conv3's loop */
+            TRY(op_pair(m, b, m->t2, x, y, B, ho, wo, h, w));
+        } else {
+            ep.scale = c3->scale; ep.shift = c3->shift; ep.residual = shortcut;
+            TRY(op_conv(m, c3, m->t2, y, B, ho, wo, &ep, -1));
+        }
     } else {
         if (b->ds >= 0) {
             const rn_conv *cd = &m->convs[b->ds];
@@ -708,7 +802,17 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
             for (r = 0; r < 4 && st == RN_OK; ++r) {
                 float t = 0.f;
                 st = rn_event_record(m->ctx, e0);
-                if (st == RN_OK)
+                if (st == RN_OK && k->pair_block >= 0) {
+                    const rn_block *pb = &m->blocks[k->pair_block];
+                    const rn_conv *cd = &m->convs[pb->ds];
+                    rn_conv_second second;
+                    second.inp = k->x2; second.in_channels = cd->cin; second.H = k->H2;
+                    second.W = k->W2; second.stride = cd->stride;
+                    st = rn_conv2d_nhwc_pair_forward_dt(m->ctx, m->dtype, m->dtype, k->x, k->y,
+                                                        pb->pair_packed, cv->k, cv->stride, k->pad,
+                                                        ho, wo, k->B, cv->cin, cv->cout, k->H, k->W,
+                                                        &second, &k->ep);
+                } else if (st == RN_OK)
                     st = rn_conv2d_nhwc_forward_dt(m->ctx, m->dtype, m->dtype, k->x, k->y, cv->packed,
                                                    cv->k, cv->stride, k->pad, ho, wo, k->B, cv->cin,
                                                    cv->cout, k->H, k->W, k->has_ep ? &k->ep : NULL);
@@ -721,7 +825,10 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
                 best_c = c;
             }
         }
-        cv->tile = best_c;
+        if (k->pair_block >= 0)
+            m->blocks[k->pair_block].pair_tile = best_c;
+        else
+            cv->tile = best_c;
     }
     rn_ctx_set_conv_tile(m->ctx, 0);
     rn_event_destroy(e0);

@@ -261,6 +261,11 @@ class NativeModel:
                                       L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS),
                 "rn_model_tune", self.ctx.handle)
 
+    def set_pair_fusion(self, on: bool) -> None:
+        """Fused mode: conv3 + downsample of a stage's first block as one contraction (default
+        on) or as two launches with the downsample tensor as the residual."""
+        L.check(L.lib().rn_model_set_pair_fusion(self.handle, int(on)), "rn_model_set_pair_fusion")
+
     def set_profiling(self, on: bool) -> None:
         L.check(L.lib().rn_model_set_profiling(self.handle, int(on)), "rn_model_set_profiling")
 

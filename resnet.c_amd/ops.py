@@ -231,6 +231,46 @@ def conv2d_nhwc_bf16(x, w, stride=1, pad=0, scale=None, shift=None, residual=Non
     return y.reshape(B, ho, wo, Cout).transpose(0, 3, 1, 2).copy()
 
 
+def conv2d_nhwc_pair(x, w, x2, w2, stride=1, pad=0, stride2=1, scale=None, scale2=None, shift=None,
+                     residual=None, relu_: bool = False, bf16: bool = False) -> np.ndarray:
+    """epilogue(conv(x, w * scale) + conv1x1(x2, w2 * scale2)) as ONE contraction:
+    rn_conv2d_pack_weight_pair_dt + rn_conv2d_nhwc_pair_forward_dt.  NCHW fp32 host arrays."""
+    from .tensor import _DeviceBuffer
+    ctx, lib = get_ctx(), L.lib()
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    _, Cin2, H2, W2 = x2.shape
+    ho, wo = conv_output_size(H, k, stride, pad), conv_output_size(W, k, stride, pad)
+    dt, es = (L.RN_DTYPE_BF16, 2) if bf16 else (L.RN_DTYPE_F32, 4)
+
+    def up_act(a):
+        a = np.asarray(a, dtype=np.float32).transpose(0, 2, 3, 1)
+        return _up_raw(to_bf16_bits(a) if bf16 else a)
+
+    dx, dx2 = up_act(x), up_act(x2)
+    dw, dw2 = _up(w, "nchw"), _up(w2, "nchw")
+    keep = [_up(v, "nchw") if v is not None else None for v in (scale, scale2, shift)]
+    pn = int(lib.rn_conv2d_packed_pair_weight_numel(Cin, Cout, k, Cin2))
+    packed = _DeviceBuffer(ctx, pn * es)
+    L.check(lib.rn_conv2d_pack_weight_pair_dt(ctx.handle, dt, dw.data(),
+                                              keep[0].data() if keep[0] else None, dw2.data(),
+                                              keep[1].data() if keep[1] else None, packed.ptr, Cin,
+                                              Cout, k, Cin2), "pack_pair", ctx.handle)
+    dres = up_act(residual) if residual is not None else None
+    ep = L.Epilogue(None, keep[2].data() if keep[2] else None, dres.ptr if dres else None,
+                    int(relu_))
+    second = L.ConvSecond(dx2.ptr, Cin2, H2, W2, stride2)
+    n_out = B * Cout * ho * wo
+    out = _DeviceBuffer(ctx, n_out * es)
+    L.check(lib.rn_conv2d_nhwc_pair_forward_dt(ctx.handle, dt, dt, dx.ptr, out.ptr, packed.ptr, k,
+                                               stride, pad, ho, wo, B, Cin, Cout, H, W,
+                                               ctypes.byref(second), ctypes.byref(ep)),
+            "rn_conv2d_nhwc_pair_forward_dt", ctx.handle)
+    ctx.sync()
+    y = from_bf16_bits(_down_raw(out, np.uint16, n_out)) if bf16 else _down_raw(out, np.float32, n_out)
+    return y.reshape(B, ho, wo, Cout).transpose(0, 3, 1, 2).copy()
+
+
 def pool_nhwc_bf16(x, k, stride=1, pad=0, is_max=True) -> np.ndarray:
     from .tensor import _DeviceBuffer
     ctx, lib = get_ctx(), L.lib()

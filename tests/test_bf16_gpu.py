@@ -55,6 +55,22 @@ def test_bf16_fused_epilogue():
     assert np.abs(got - want).max() <= 2 ** -8 * np.abs(want).max() + 1e-5
 
 
+def test_bf16_conv_pair():
+    B, Cin, Cout, H, W, Cin2, s2 = 2, 64, 128, 7, 7, 128, 2
+    t, w = rnd((B, Cin, H, W), 71), rnd((Cout, Cin, 1, 1), 72)
+    x2, w2 = rnd((B, Cin2, 13, 13), 73), rnd((Cout, Cin2, 1, 1), 74)
+    g = np.random.default_rng(75)
+    sc1, sc2 = g.random(Cout, dtype=np.float32) + 0.5, g.random(Cout, dtype=np.float32) + 0.5
+    shift = g.standard_normal(Cout, dtype=np.float32)
+    # what the kernel multiplies: bf16(activations) x bf16(fl32(w * scale)), fp32 accumulate
+    tb, xb = ops.bf16_round(t), ops.bf16_round(x2)
+    w1b = ops.bf16_round(w * sc1[:, None, None, None])
+    w2b = ops.bf16_round(w2 * sc2[:, None, None, None])
+    want = O.relu_(O.conv2d(tb, w1b, 1, 0) + O.conv2d(xb, w2b, s2, 0) + shift[None, :, None, None])
+    got = ops.conv2d_nhwc_pair(t, w, x2, w2, 1, 0, s2, sc1, sc2, shift, None, True, bf16=True)
+    np.testing.assert_allclose(got, ops.bf16_round(want), rtol=2 ** -7, atol=1e-2)
+
+
 def test_bf16_pools():
     x = rnd((2, 64, 14, 14), 5)
     xb = ops.bf16_round(x)

@@ -252,3 +252,24 @@ def test_captured_forward_replays_bit_exact(model50, finch, fused):
     with pytest.raises(R.RnError):
         R.Graph(model50, xd.data(), B, out.data(), fused=fused)
     model50.set_profiling(False)
+
+
+def test_pair_fusion_changes_launches_not_results(model50, finch):
+    """conv3 + downsample as one contraction (the default) against the two-launch form: four
+    launches fewer, same logits within the fold's rounding, same top-1."""
+    x = R.weights.generate_input(3, seed=77)
+    x[0] = finch[0]
+    with_pair = model50.forward(x, fused=True)
+    model50.set_profiling(True)
+    model50.forward(x, fused=True)
+    n_pair = len(model50.profile())
+    model50.set_pair_fusion(False)
+    try:
+        without = model50.forward(x, fused=True)
+        n_plain = len(model50.profile())
+    finally:
+        model50.set_pair_fusion(True)
+        model50.set_profiling(False)
+    assert n_plain - n_pair == 4
+    assert np.abs(with_pair - without).max() <= 2e-5
+    assert np.array_equal(with_pair.argmax(1), without.argmax(1))

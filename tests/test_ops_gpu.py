@@ -111,6 +111,45 @@ def test_fused_epilogue_matches_unfused_sequence(case):
     assert_close(got, want, Cin * k * k + 4)
 
 
+@pytest.mark.parametrize("case", [
+    # B, Cin, Cout, H, W, k, pad, Cin2, stride2   (first conv stride 1, as conv3 of a block)
+    (2, 64, 256, 14, 14, 1, 0, 64, 1),     # layer1.0: conv3 + downsample, both 1x1 stride 1
+    (2, 128, 512, 7, 7, 1, 0, 256, 2),     # layer2.0: downsample reads every second pixel
+    (1, 32, 40, 5, 6, 3, 1, 96, 2),        # 3x3 first conv, ragged M and Cout, odd second image
+    (3, 64, 64, 9, 9, 1, 0, 32, 1),
+])
+def test_conv_pair_is_the_sum_of_both_branches(case):
+    """rn_conv2d_nhwc_pair_forward_dt: relu(bn3(conv3(t)) + bnd(convd(x))) from one K loop.  The
+    scales are folded into the weight rows, so the reference applies them the same way."""
+    B, Cin, Cout, H, W, k, p, Cin2, s2 = case
+    seed = 300 + sum(case)
+    t, w = rnd((B, Cin, H, W), seed), rnd((Cout, Cin, k, k), seed + 1)
+    H2, W2 = (H - 1) * s2 + 1 + (s2 - 1), (W - 1) * s2 + 1   # ragged: last row unused when s2 = 2
+    x2, w2 = rnd((B, Cin2, H2, W2), seed + 2), rnd((Cout, Cin2, 1, 1), seed + 3)
+    g = np.random.default_rng(seed + 4)
+    sc1, sc2 = g.random(Cout, dtype=np.float32) + 0.5, g.random(Cout, dtype=np.float32) + 0.5
+    shift = g.standard_normal(Cout, dtype=np.float32)
+    a = O.conv2d(t, w * sc1[:, None, None, None], 1, p)
+    b = O.conv2d(x2, w2 * sc2[:, None, None, None], s2, 0)
+    assert a.shape == b.shape
+    want = O.relu_(a + b + shift[None, :, None, None])
+    got = ops.conv2d_nhwc_pair(t, w, x2, w2, 1, p, s2, sc1, sc2, shift, None, True)
+    assert_close(got, want, Cin * k * k + Cin2 + 4)
+    # without scales / shift / relu, plus a residual
+    res = rnd(a.shape, seed + 5)
+    want2 = O.conv2d(t, w, 1, p) + O.conv2d(x2, w2, s2, 0) + res
+    got2 = ops.conv2d_nhwc_pair(t, w, x2, w2, 1, p, s2, residual=res)
+    assert_close(got2, want2, Cin * k * k + Cin2 + 4)
+
+
+def test_conv_pair_rejects_what_it_cannot_do():
+    t, w = rnd((1, 32, 4, 4), 1), rnd((32, 32, 1, 1), 2)
+    with pytest.raises(R.RnError):   # second channel count not a multiple of 32
+        ops.conv2d_nhwc_pair(t, w, rnd((1, 16, 4, 4), 3), rnd((32, 16, 1, 1), 4))
+    with pytest.raises(R.RnError):   # second convolution gives another output size
+        ops.conv2d_nhwc_pair(t, w, rnd((1, 32, 9, 9), 3), rnd((32, 32, 1, 1), 4), stride2=3)
+
+
 def test_batchnorm_fold_entry_point():
     import ctypes
     from resnet_c_amd import _lib as L
