@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Per-kernel durations of the TIMED forwards in a rocprofv3 --kernel-trace of bench.py.
+
+bench.py launches every tile candidate while it tunes, so the --stats table of the whole
+process mixes those launches in.  This takes the last F forwards of the trace (F = --steps +
+--profile-forwards; a forward = the launches between two input-layout kernels) and reports,
+per kernel family, launches per forward and the average duration: the number bench.py's
+`roofline` is computed from (its HIP events) must agree with it.
+
+    python tools/ktrace_summary.py <dir with *_kernel_trace.csv> F [out.json]"""
+import csv, glob, json, os, sys
+
+
+def family(name):
+    if "conv_gemm_kernel" in name:
+        return "conv_gemm_kernel"
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    return n.split("(")[0].split("<")[0]
+
+
+def main():
+    d, F = sys.argv[1], int(sys.argv[2])
+    f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"])
+                   for r in csv.DictReader(open(f))), key=lambda r: r[0])
+    starts = [i for i, r in enumerate(rows) if "nchw_to_nhwc" in r[2]]
+    first = starts[-F]
+    sel = rows[first:]
+    fam = {}
+    for s, e, n in sel:
+        a = fam.setdefault(family(n), [0, 0])
+        a[0] += 1
+        a[1] += e - s
+    span_ns = sel[-1][1] - sel[0][0]
+    out = {"forwards": F, "span_ms_per_forward": span_ns / F / 1e6,
+           "kernels": {k: {"launches_per_forward": v[0] / F, "avg_us": v[1] / v[0] / 1e3,
+                           "ms_per_forward": v[1] / F / 1e6} for k, v in sorted(fam.items())}}
+    print(json.dumps(out, indent=1))
+    if len(sys.argv) > 3:
+        json.dump(out, open(sys.argv[3], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
