@@ -247,6 +247,9 @@ RN_API int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float
  * (rn_conv2d_nhwc_pair_forward_dt); on by default, off = downsample first, then conv3 with it
  * as the residual.  Changing it invalidates the tuned tiles. */
 RN_API int rn_model_set_pair_fusion(rn_model *m, int on);
+/* fp32 models: stem through rn_conv2d_nhwc_exact_forward (K = 160; default) or through the
+ * 4-channel / 8-slot form of rn_conv2d_nhwc_forward (K = 224).  Invalidates the tuned tiles. */
+RN_API int rn_model_set_stem_exact(rn_model *m, int on);
 RN_API int rn_model_set_profiling(rn_model *m, int on);
 /* after a profiled forward + rn_sync: number of ops, then one record per op */
 RN_API uint64_t rn_model_profile_count(const rn_model *m);
@@ -254,6 +257,23 @@ RN_API int rn_model_profile_get(const rn_model *m, uint64_t index, const char **
                                 const char **layer_name, float *ms, double *flops,
                                 double *bytes);
 RN_API uint64_t rn_model_activation_bytes(const rn_model *m);
+
+/* ---- exact-K small-Cin form (fp32): the 7x7x3 stem as K = 147 -> 160 -----------------
+ * rn_conv2d_nhwc_forward pads a 3-channel image to 4 channels and 8 kernel-column slots
+ * (K = 7*32 = 224 per output for 147 real products).  This form reads a physically padded
+ * [B,Hp,Wp,Cin] image (rn_nchw_to_nhwc_pad_dt with Cpad = Cin and border = the convolution's
+ * padding; Hp = H + 2*pad) with dword gathers and packs K = k*k*Cin contiguously, rounded up
+ * to a multiple of 32 — 5 K tiles instead of 7 for the ResNet stem (conv1, main.cu:111). */
+RN_API uint64_t rn_conv2d_packed_weight_numel_exact(uint64_t in_channels, uint64_t out_channels,
+                                                    uint64_t kernel_size);
+RN_API int rn_conv2d_pack_weight_exact(rn_ctx *ctx, const float *weight_oihw, float *packed,
+                                       uint64_t in_channels, uint64_t out_channels,
+                                       uint64_t kernel_size);
+RN_API int rn_conv2d_nhwc_exact_forward(rn_ctx *ctx, const float *inp_padded, float *out,
+                                        const float *packed_exact_weight, uint64_t kernel_size,
+                                        uint64_t stride, uint64_t h_out, uint64_t w_out,
+                                        uint64_t B, uint64_t in_channels, uint64_t out_channels,
+                                        uint64_t Hp, uint64_t Wp, const rn_epilogue *epilogue);
 
 /* ---- fused pair: out = epilogue(conv(inp, W1) + conv1x1(inp2, W2)) ------------------
  * One contraction whose K loop runs through both convolutions: the bottleneck's conv3 and the

@@ -86,12 +86,17 @@ SIGNATURES = {
     "rn_nchw_to_nhwc_pad_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 6),
     "rn_conv2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, c_int, fptr, fptr, fptr] + [u64] * 10
                                   + [POINTER(Epilogue)]),
+    "rn_conv2d_packed_weight_numel_exact": (u64, [u64, u64, u64]),
+    "rn_conv2d_pack_weight_exact": (c_int, [c_void_p, fptr, fptr, u64, u64, u64]),
+    "rn_conv2d_nhwc_exact_forward": (c_int, [c_void_p, fptr, fptr, fptr] + [u64] * 9
+                                     + [POINTER(Epilogue)]),
     "rn_conv2d_packed_pair_weight_numel": (u64, [u64, u64, u64, u64]),
     "rn_conv2d_pack_weight_pair_dt": (c_int, [c_void_p, c_int, fptr, fptr, fptr, fptr, fptr]
                                       + [u64] * 4),
     "rn_conv2d_nhwc_pair_forward_dt": (c_int, [c_void_p, c_int, c_int, fptr, fptr, fptr] + [u64] * 10
                                        + [POINTER(ConvSecond), POINTER(Epilogue)]),
     "rn_model_set_pair_fusion": (c_int, [c_void_p, c_int]),
+    "rn_model_set_stem_exact": (c_int, [c_void_p, c_int]),
     "rn_maxpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),
     "rn_avgpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),
     "rn_model_create": (c_int, [c_void_p, POINTER(c_void_p), c_int]),

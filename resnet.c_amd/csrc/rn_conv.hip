@@ -93,6 +93,11 @@ struct GemmParams {
     // 1x1 / padding-0 convolution of the same output geometry (the downsample branch)
     const void *in2;
     int in2_bytes, H2, W2, Cs2, stride2, nk1;
+    // exact-K small-Cin form (XK kernels only): K index q = (kh*KW + kw)*Cin + c over a
+    // physically padded image; element q of an A row sits q + (q / kc) * kskip floats after
+    // the row's first element (kc = KW*Cin, kskip = (W - KW)*Cin), zero weight past kreal
+    int kc, kskip, kreal;
+    unsigned mul_kc, shr_kc;
     // diagnostic only (tools/conv_stamps.py): 16 stamp slots per block, or null
     unsigned long long *stamps;
 };
@@ -211,7 +216,8 @@ struct OutVec<bf16_t> {
 
 // T: element type of activations and weights; TO: element type of the output (and residual)
 // DUAL: the K loop continues through a second (input, weight-row tail) pair, see GemmParams
-template <typename T, typename TO, int BM, int BN, bool DUAL = false>
+// XK: exact-K small-Cin form (the 7x7x3 stem as K = 147 -> 160 instead of 224), fp32 only
+template <typename T, typename TO, int BM, int BN, bool DUAL = false, bool XK = false>
 __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 ? 3 : 2)) void conv_gemm_kernel(const GemmParams p)
 {
     constexpr int CH = Elem<T>::CH, ES = (int)sizeof(T);
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
                 const int ih0 = oh * p.stride - p.pad;
                 const int iw0 = ow * p.stride - p.pad;
                 const int iwc = iw0 + c * p.chunk_dw;
-                a_off[j] = (((b * p.H + ih0) * p.W + iw0) * p.Cs + c * CH) * ES;
+                a_off[j] = (((b * p.H + ih0) * p.W + iw0) * p.Cs + (XK ? 0 : c * CH)) * ES;
                 const int rlo = max(0, -ih0), rhi = min(p.KH, p.H - ih0);
                 const int clo = max(0, -iwc), chi = min(p.KW, p.W - iwc);
                 const int rm = rhi > rlo ? ((1 << rhi) - 1) & ~((1 << rlo) - 1) : 0;
@@ -305,6 +311,28 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
     // costs no vector ALU work at all (vector ALU work competes with the fp32 MFMA stream).
     auto load_tile = [&](int kt, u32x4 (&xa)[AP], u32x4 (&xb)[BP]) {
         const unsigned s_kt = (unsigned)__builtin_amdgcn_readfirstlane(kt);
+        if constexpr (XK) {
+            // four dword gathers per chunk: the chunk's K indices may straddle a kernel row
+            int eoff[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned q = s_kt * 32u + (unsigned)(c * 4 + e);
+                const unsigned kh = __umulhi(q, p.mul_kc) >> p.shr_kc;
+                eoff[e] = (int)q < p.kreal ? (int)(q + kh * (unsigned)p.kskip) * 4 : kOob;
+            }
+#pragma unroll
+            for (int j = 0; j < AP; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int off = (a_mask[j] != 0 && eoff[e] != kOob) ? a_off[j] + eoff[e] : kOob;
+                    xa[j][e] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, off, 0, 0);
+                }
+            const int soff_b = (int)s_kt * 128;
+#pragma unroll
+            for (int j = 0; j < BP; ++j)
+                xb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_off[j], soff_b, 0);
+            return;
+        }
         int s_cs;
         __amdgpu_buffer_rsrc_t rs = rsrc_a;
         if (DUAL && s_kt >= (unsigned)p.nk1) {
@@ -691,13 +719,13 @@ void fast_div(unsigned d, unsigned *mul, unsigned *shr)
 }
 
 // Blocks of one instantiation that fit a CU at once (registers and LDS), asked once.
-template <typename T, typename TO, int BM, int BN, bool DUAL>
+template <typename T, typename TO, int BM, int BN, bool DUAL, bool XK>
 int resident_blocks_per_cu()
 {
     static int cached = 0;
     if (cached == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_kernel<T, TO, BM, BN, DUAL>, 256,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_kernel<T, TO, BM, BN, DUAL, XK>, 256,
                                                          0) != hipSuccess ||
             nb < 1)
             nb = 1;
@@ -706,28 +734,28 @@ int resident_blocks_per_cu()
     return cached;
 }
 
-template <typename T, typename TO, int BM, int BN, bool DUAL>
+template <typename T, typename TO, int BM, int BN, bool DUAL, bool XK>
 void launch_one(rn_ctx *ctx, GemmParams &p, bool persistent)
 {
     unsigned grid = p.total_tiles;
     if (persistent) {
-        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN, DUAL>();
+        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN, DUAL, XK>();
         if (grid > slots) grid = slots;
     }
-    conv_gemm_kernel<T, TO, BM, BN, DUAL><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
+    conv_gemm_kernel<T, TO, BM, BN, DUAL, XK><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
 }
 
-template <typename T, typename TO, bool DUAL = false>
+template <typename T, typename TO, bool DUAL = false, bool XK = false>
 void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent)
 {
     if (BMsel == 128 && BNsel == 128)
-        launch_one<T, TO, 128, 128, DUAL>(ctx, p, persistent);
+        launch_one<T, TO, 128, 128, DUAL, XK>(ctx, p, persistent);
     else if (BMsel == 128 && BNsel == 64)
-        launch_one<T, TO, 128, 64, DUAL>(ctx, p, persistent);
+        launch_one<T, TO, 128, 64, DUAL, XK>(ctx, p, persistent);
     else if (BMsel == 64 && BNsel == 128)
-        launch_one<T, TO, 64, 128, DUAL>(ctx, p, persistent);
+        launch_one<T, TO, 64, 128, DUAL, XK>(ctx, p, persistent);
     else
-        launch_one<T, TO, 64, 64, DUAL>(ctx, p, persistent);
+        launch_one<T, TO, 64, 64, DUAL, XK>(ctx, p, persistent);
 }
 
 // GEMM launch on NHWC data with packed weights.  Caller has checked eligibility.
@@ -735,7 +763,8 @@ void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persist
 int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, const void *packed,
                 uint64_t k, uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out,
                 uint64_t B, uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W,
-                const rn_epilogue *ep, const char *what, const rn_conv_second *second = nullptr)
+                const rn_epilogue *ep, const char *what, const rn_conv_second *second = nullptr,
+                bool exact = false)
 {
     const int es = dt_in == RN_DTYPE_BF16 ? 2 : 4;
     const int bke = 128 / es;
@@ -747,7 +776,7 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     p.shift = ep ? ep->shift : nullptr;
     p.residual = ep ? ep->residual : nullptr;
     p.relu = ep ? ep->relu : 0;
-    const bool c4 = rn_conv_is_c4(Cin, k);
+    const bool c4 = !exact && rn_conv_is_c4(Cin, k);
     p.H = (int)H;
     p.W = (int)W;
     p.Cs = c4 ? 4 : (int)Cin;
@@ -776,6 +805,17 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
         p.nk += (int)(second->in_channels / bke);
     }
     p.Ktot = p.nk * bke;
+    p.kc = p.kskip = p.kreal = 0;
+    p.mul_kc = p.shr_kc = 0;
+    if (exact) {
+        p.kreal = (int)(k * k * Cin);
+        p.kc = (int)(k * Cin);
+        p.kskip = (int)((W - k) * Cin);
+        p.nk = p.nk1 = (int)rn_ceil_div((uint64_t)p.kreal, 32);
+        p.Ktot = p.nk * 32;
+        p.cseg = 1;
+        fast_div((unsigned)p.kc, &p.mul_kc, &p.shr_kc);
+    }
     p.HoWo = p.Ho * p.Wo;
     fast_div((unsigned)p.HoWo, &p.mul_hw, &p.shr_hw);
     fast_div((unsigned)p.Wo, &p.mul_w, &p.shr_w);
@@ -820,7 +860,9 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     const uint64_t total = tiles_m * tiles_n;
     RN_REQUIRE(ctx, fits_i32(total), "too many tiles");
     p.total_tiles = (unsigned)total;
-    if (second && dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)
+    if (exact)
+        launch_tiles<float, float, false, true>(ctx, p, BMsel, BNsel, persistent);
+    else if (second && dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)
         launch_tiles<float, float, true>(ctx, p, BMsel, BNsel, persistent);
     else if (second && dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_BF16)
         launch_tiles<bf16_t, bf16_t, true>(ctx, p, BMsel, BNsel, persistent);
@@ -1013,6 +1055,39 @@ int rn_conv2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void 
     return launch_gemm(ctx, RN_DTYPE_BF16, out_dtype, inp, out, packed_weight, kernel_size, stride,
                        padding, h_out, w_out, B, in_channels, out_channels, H, W, epilogue,
                        "rn_conv2d_nhwc_forward_dt");
+}
+
+int rn_conv2d_nhwc_exact_forward(rn_ctx *ctx, const float *inp_padded, float *out,
+                                 const float *packed_exact_weight, uint64_t kernel_size,
+                                 uint64_t stride, uint64_t h_out, uint64_t w_out, uint64_t B,
+                                 uint64_t in_channels, uint64_t out_channels, uint64_t Hp,
+                                 uint64_t Wp, const rn_epilogue *epilogue)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (B * out_channels * h_out * w_out == 0) return RN_OK;
+    RN_REQUIRE(ctx, inp_padded && out && packed_exact_weight && inp_padded != out,
+               "null or aliased tensor");
+    RN_REQUIRE(ctx, kernel_size >= 1 && kernel_size <= 15 && stride >= 1 && stride < (1u << 12) &&
+                        in_channels >= 1 && in_channels <= 16,
+               "kernel_size / stride / in_channels out of range");
+    RN_REQUIRE(ctx, Hp >= kernel_size && Wp >= kernel_size &&
+                        rn_conv_output_size(Hp, kernel_size, stride, 0) == h_out &&
+                        rn_conv_output_size(Wp, kernel_size, stride, 0) == w_out,
+               "h_out / w_out do not match the padded image");
+    const uint64_t ktot = rn_ceil_div(kernel_size * kernel_size * in_channels, 32) * 32;
+    RN_REQUIRE(ctx, B * Hp * Wp * in_channels < (1ull << 29) && out_channels * ktot < (1ull << 29) &&
+                        B * h_out * w_out * out_channels < (1ull << 29),
+               "tensor too large");
+    RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(out) |
+                      reinterpret_cast<uintptr_t>(packed_exact_weight)) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(inp_padded) & 3) == 0,
+               "misaligned tensor");
+    if (epilogue && epilogue->residual)
+        RN_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(epilogue->residual) & 15) == 0,
+                   "misaligned residual");
+    return launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, inp_padded, out, packed_exact_weight,
+                       kernel_size, stride, 0, h_out, w_out, B, in_channels, out_channels, Hp, Wp,
+                       epilogue, "rn_conv2d_nhwc_exact_forward", nullptr, true);
 }
 
 int rn_conv2d_nhwc_pair_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void *inp, void *out,

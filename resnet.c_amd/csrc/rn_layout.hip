@@ -81,6 +81,26 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
     }
 }
 
+// exact-K small-Cin panel: row oc = [kh][kw][Cin] packed without slots, zero-padded to Kpad
+__global__ __launch_bounds__(256) void pack_weight_exact_kernel(const float *__restrict__ w,
+                                                                float *__restrict__ packed,
+                                                                uint32_t Cin, uint32_t k,
+                                                                uint32_t Kpad, uint64_t total)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    const uint32_t kk = k * k, kreal = kk * Cin;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
+        const uint32_t q = (uint32_t)(i % Kpad);
+        const uint64_t oc = i / Kpad;
+        float v = 0.f;
+        if (q < kreal) {
+            const uint32_t ic = q % Cin, tap = q / Cin;
+            v = w[(oc * Cin + ic) * kk + tap];
+        }
+        packed[i] = v;
+    }
+}
+
 // fused pair: row oc = [kh][kw][Cin] of w1 * s1[oc], then [Cin2] of the 1x1 w2 * s2[oc]
 template <typename TP>
 __global__ __launch_bounds__(256) void pack_weight_pair_kernel(
@@ -186,6 +206,39 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_border_kernel(const float *_
     }
 }
 
+// same, fp32, one 16-byte store per thread (needs (H+2b)*(W+2b)*Cpad % 4 == 0); divisions by
+// Cpad and W+2b as multiply-high (n / d == umulhi(n, mul) >> shr for n < 2^31)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_border_f4_kernel(
+    const float *__restrict__ src, float4 *__restrict__ dst, uint32_t C, uint32_t H, uint32_t W,
+    uint32_t Cpad, uint32_t border, uint32_t Wp, uint32_t n4, uint32_t mul_c, uint32_t shr_c,
+    uint32_t mul_w, uint32_t shr_w)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const uint64_t b = blockIdx.y;
+    const float *img = src + b * C * H * W;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t idx = 4 * i + e;
+        const uint32_t pix = Cpad == 1 ? idx : __umulhi(idx, mul_c) >> shr_c;
+        const uint32_t c = idx - pix * Cpad;
+        const uint32_t hp = __umulhi(pix, mul_w) >> shr_w;
+        const uint32_t h = hp - border, w = pix - hp * Wp - border;  // wrap = out of range
+        v[e] = (c < C && h < H && w < W) ? img[(c * H + h) * W + w] : 0.f;
+    }
+    dst[b * n4 + i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+void magic_div(uint32_t d, uint32_t *mul, uint32_t *shr)
+{
+    uint32_t lg = 0;
+    while ((1u << lg) < d) ++lg;
+    const uint32_t p = 31 + lg;
+    *mul = (uint32_t)(((1ull << p) + d - 1) / d);
+    *shr = p - 32;
+}
+
 }  // namespace
 
 bool rn_conv_is_c4(uint64_t Cin, uint64_t k) { return Cin <= 4 && k <= 8; }
@@ -220,6 +273,28 @@ int rn_conv2d_pack_weight(rn_ctx *ctx, const float *weight_oihw, float *packed,
             weight_oihw, packed, (uint32_t)in_channels, (uint32_t)kernel_size, total);
     }
     return rn_after_launch(ctx, "rn_conv2d_pack_weight");
+}
+
+uint64_t rn_conv2d_packed_weight_numel_exact(uint64_t in_channels, uint64_t out_channels,
+                                             uint64_t kernel_size)
+{
+    return out_channels * rn_ceil_div(kernel_size * kernel_size * in_channels, 32) * 32;
+}
+
+int rn_conv2d_pack_weight_exact(rn_ctx *ctx, const float *weight_oihw, float *packed,
+                                uint64_t in_channels, uint64_t out_channels, uint64_t kernel_size)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    const uint64_t total =
+        rn_conv2d_packed_weight_numel_exact(in_channels, out_channels, kernel_size);
+    if (total == 0) return RN_OK;
+    RN_REQUIRE(ctx, weight_oihw && packed && weight_oihw != packed, "null or aliased tensor");
+    RN_REQUIRE(ctx, in_channels >= 1 && in_channels <= 16 && kernel_size >= 1 && kernel_size <= 15,
+               "in_channels / kernel_size out of range");
+    pack_weight_exact_kernel<<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
+        weight_oihw, packed, (uint32_t)in_channels, (uint32_t)kernel_size,
+        (uint32_t)(total / out_channels), total);
+    return rn_after_launch(ctx, "rn_conv2d_pack_weight_exact");
 }
 
 uint64_t rn_conv2d_packed_pair_weight_numel(uint64_t in_channels, uint64_t out_channels,
@@ -302,6 +377,21 @@ int rn_nchw_to_nhwc_pad_dt(rn_ctx *ctx, int dtype, const float *src, void *dst, 
         nchw_to_nhwc_border_kernel<bf16_t><<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
             src, (bf16_t *)dst, (uint32_t)C, (uint32_t)H, (uint32_t)W, (uint32_t)Cpad,
             (uint32_t)border, total);
+    } else if (dtype == RN_DTYPE_F32 && ((H + 2 * border) * (W + 2 * border) * Cpad) % 4 == 0 &&
+               (H + 2 * border) * (W + 2 * border) * Cpad < (1ull << 31) && Cpad >= 1 &&
+               W + 2 * border >= 2 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        const uint32_t n4 = (uint32_t)((H + 2 * border) * (W + 2 * border) * Cpad / 4);
+        uint32_t mc = 0, sc = 0, mw = 0, sw = 0;
+        if (Cpad > 1) magic_div((uint32_t)Cpad, &mc, &sc);
+        magic_div((uint32_t)(W + 2 * border), &mw, &sw);
+        for (uint64_t b0 = 0; b0 < B; b0 += 65535) {
+            const uint64_t nb = (B - b0) < 65535 ? (B - b0) : 65535;
+            nchw_to_nhwc_border_f4_kernel<<<dim3((n4 + 255) / 256, (unsigned)nb), 256, 0,
+                                            ctx->stream>>>(
+                src + b0 * C * H * W, (float4 *)dst + b0 * n4, (uint32_t)C, (uint32_t)H,
+                (uint32_t)W, (uint32_t)Cpad, (uint32_t)border, (uint32_t)(W + 2 * border), n4, mc,
+                sc, mw, sw);
+        }
     } else if (dtype == RN_DTYPE_F32) {
         nchw_to_nhwc_border_kernel<float><<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
             src, (float *)dst, (uint32_t)C, (uint32_t)H, (uint32_t)W, (uint32_t)Cpad,

@@ -68,6 +68,7 @@ typedef struct {
 typedef struct {
     int conv;
     int pair_block; /* >= 0: the fused conv3 + downsample call of that block (x2, H2, W2) */
+    int exact;      /* the stem in its exact-K form (x = physically padded image) */
     const void *x, *x2;
     void *y;
     uint64_t B, H, W, pad, H2, W2;
@@ -89,6 +90,8 @@ struct rn_model {
     int finalized;
     int dtype;        /* storage type of activations and packed weights */
     int pair_fusion;  /* fused mode: conv3 + downsample as one contraction (default on) */
+    int stem_exact;   /* fp32: stem in the exact-K form, K = 160 instead of 224 (default on) */
+    float *stem_packed_exact;
     void *fc_packed;  /* fc.weight in the model dtype (bf16 models only) */
     /* activation arenas, sized for batch_cap images */
     uint64_t batch_cap;
@@ -157,7 +160,7 @@ int rn_model_create(rn_ctx *ctx, rn_model **out, int arch)
     else if (arch == 152) d = d152;
     else return RN_ERR_UNSUPPORTED;
     m = (rn_model *)calloc(1, sizeof(rn_model));
-    if (m) m->pair_fusion = 1;
+    if (m) m->pair_fusion = m->stem_exact = 1;
     if (!m) return RN_ERR_NOMEM;
     m->ctx = ctx;
     m->arch = arch;
@@ -258,6 +261,7 @@ int rn_model_destroy(rn_model *m)
         }
     }
     rn_free(m->ctx, m->fc_packed);
+    rn_free(m->ctx, m->stem_packed_exact);
     free_acts(m);
     free_prof(m);
     free(m->params);
@@ -375,6 +379,18 @@ int rn_model_finalize(rn_model *m)
                                  cv->shift, cv->cout);
         if (st != RN_OK) return st;
     }
+    if (m->dtype == RN_DTYPE_F32) {
+        const rn_conv *stem = &m->convs[0];
+        if (!m->stem_packed_exact) {
+            st = rn_malloc(m->ctx, (void **)&m->stem_packed_exact,
+                           rn_conv2d_packed_weight_numel_exact(stem->cin, stem->cout, stem->k) *
+                               sizeof(float));
+            if (st != RN_OK) return st;
+        }
+        st = rn_conv2d_pack_weight_exact(m->ctx, m->params[stem->w].dev, m->stem_packed_exact,
+                                         stem->cin, stem->cout, stem->k);
+        if (st != RN_OK) return st;
+    }
     for (c = 0; c < m->n_blocks; ++c) {
         rn_block *b = &m->blocks[c];
         const rn_conv *c3, *cd;
@@ -455,6 +471,14 @@ int rn_model_set_pair_fusion(rn_model *m, int on)
     return RN_OK;
 }
 
+int rn_model_set_stem_exact(rn_model *m, int on)
+{
+    if (!m) return RN_ERR_INVALID;
+    m->stem_exact = on ? 1 : 0;
+    m->tuned_B = 0;
+    return RN_OK;
+}
+
 int rn_model_profiling_enabled(const rn_model *m) { return m ? m->profiling : 0; }
 
 /* ---- profiling --------------------------------------------------------- */
@@ -530,11 +554,14 @@ int rn_model_profile_get(const rn_model *m, uint64_t index, const char **op_name
 
 /* ---- ops with profiling brackets --------------------------------------- */
 /* pad_override >= 0 replaces the layer's padding (the bf16 stem reads an image that carries
- * its own zero border: H, W are then the padded sizes and the padding is 0) */
+ * its own zero border: H, W are then the padded sizes and the padding is 0); RN_PAD_EXACT: the
+ * fp32 stem in its exact-K form, x = [B,H,W,cin] physically padded */
+#define RN_PAD_EXACT (-2)
 static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint64_t B, uint64_t H,
                    uint64_t W, const rn_epilogue *ep, int64_t pad_override)
 {
-    const uint64_t pad = pad_override >= 0 ? (uint64_t)pad_override : cv->pad;
+    const int exact = pad_override == RN_PAD_EXACT;
+    const uint64_t pad = exact ? 0 : pad_override >= 0 ? (uint64_t)pad_override : cv->pad;
     const uint64_t ho = rn_conv_output_size(H, cv->k, cv->stride, pad);
     const uint64_t wo = rn_conv_output_size(W, cv->k, cv->stride, pad);
     const double M = (double)(B * ho * wo), K = (double)(cv->cin * cv->k * cv->k);
@@ -546,6 +573,7 @@ static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint6
         rn_conv_call *c = &m->calls[m->n_calls++];
         c->conv = (int)(cv - m->convs);
         c->pair_block = -1;
+        c->exact = exact;
         c->x = x;
         c->y = y;
         c->B = B;
@@ -559,9 +587,12 @@ static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint6
                    bytes));
     rn_ctx_set_conv_tile(m->ctx, (m->tuned_B == B && m->tuned_mode == m->cur_mode) ? cv->tile : 0);
     {
-        const int st = rn_conv2d_nhwc_forward_dt(m->ctx, m->dtype, m->dtype, x, y, cv->packed, cv->k,
-                                                 cv->stride, pad, ho, wo, B, cv->cin, cv->cout, H, W,
-                                                 ep);
+        const int st =
+            exact ? rn_conv2d_nhwc_exact_forward(m->ctx, (const float *)x, (float *)y,
+                                                 m->stem_packed_exact, cv->k, cv->stride, ho, wo, B,
+                                                 cv->cin, cv->cout, H, W, ep)
+                  : rn_conv2d_nhwc_forward_dt(m->ctx, m->dtype, m->dtype, x, y, cv->packed, cv->k,
+                                              cv->stride, pad, ho, wo, B, cv->cin, cv->cout, H, W, ep);
         rn_ctx_set_conv_tile(m->ctx, 0);
         if (st != RN_OK) return st;
     }
@@ -588,6 +619,7 @@ static int op_pair(rn_model *m, rn_block *b, const void *t, const void *x, void 
         rn_conv_call *c = &m->calls[m->n_calls++];
         c->conv = b->conv3;
         c->pair_block = (int)(b - m->blocks);
+        c->exact = 0;
         c->x = t; c->x2 = x; c->y = y;
         c->B = B; c->H = H; c->W = W; c->pad = 0; c->H2 = H2; c->W2 = W2;
         c->has_ep = 1;
@@ -716,17 +748,28 @@ int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *lo
                 STEP(op_conv(m, stem, m->x4, m->p1, B, H + 2 * border, W + 2 * border, &ep, 0));
             }
         } else {
-            STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0, 4.0 * (double)(B * 224 * 224 * 7)));
-            STEP(rn_nchw_to_nhwc_pad(m->ctx, input_nchw, m->x4, B, 3, H, W, 4));
+            /* exact-K form: [B,230,230,3] with a physical border; else [B,224,224,4] */
+            const uint64_t border = m->stem_exact ? stem->pad : 0;
+            const uint64_t sh = H + 2 * border, sw = W + 2 * border;
+            const int64_t form = m->stem_exact ? RN_PAD_EXACT : -1;
+            if (m->stem_exact) {
+                STEP(prof_begin(m, "nchw_to_nhwc3", "input", 0.0,
+                                4.0 * (double)B * (3.0 * 224 * 224 + 3.0 * 230 * 230)));
+                STEP(rn_nchw_to_nhwc_pad_dt(m->ctx, RN_DTYPE_F32, input_nchw, m->x4, B, 3, H, W, 3,
+                                            border));
+            } else {
+                STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0, 4.0 * (double)(B * 224 * 224 * 7)));
+                STEP(rn_nchw_to_nhwc_pad(m->ctx, input_nchw, m->x4, B, 3, H, W, 4));
+            }
             STEP(prof_end(m));
             ho = rn_conv_output_size(H, stem->k, stem->stride, stem->pad);
             wo = rn_conv_output_size(W, stem->k, stem->stride, stem->pad);
             if (mode == RN_FWD_FUSED) {
                 rn_epilogue ep;
                 ep.scale = stem->scale; ep.shift = stem->shift; ep.residual = NULL; ep.relu = 1;
-                STEP(op_conv(m, stem, m->x4, m->p1, B, H, W, &ep, -1));
+                STEP(op_conv(m, stem, m->x4, m->p1, B, sh, sw, &ep, form));
             } else {
-                STEP(op_conv(m, stem, m->x4, m->p1, B, H, W, NULL, -1));
+                STEP(op_conv(m, stem, m->x4, m->p1, B, sh, sw, NULL, form));
                 STEP(op_bn(m, stem, m->p1, B, ho * wo));
                 STEP(op_relu(m, "conv1", m->p1, B * ho * wo * 64));
             }
@@ -812,6 +855,11 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
                                                         pb->pair_packed, cv->k, cv->stride, k->pad,
                                                         ho, wo, k->B, cv->cin, cv->cout, k->H, k->W,
                                                         &second, &k->ep);
+                } else if (st == RN_OK && k->exact) {
+                    st = rn_conv2d_nhwc_exact_forward(m->ctx, (const float *)k->x, (float *)k->y,
+                                                      m->stem_packed_exact, cv->k, cv->stride, ho,
+                                                      wo, k->B, cv->cin, cv->cout, k->H, k->W,
+                                                      k->has_ep ? &k->ep : NULL);
                 } else if (st == RN_OK)
                     st = rn_conv2d_nhwc_forward_dt(m->ctx, m->dtype, m->dtype, k->x, k->y, cv->packed,
                                                    cv->k, cv->stride, k->pad, ho, wo, k->B, cv->cin,

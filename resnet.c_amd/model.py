@@ -266,6 +266,10 @@ class NativeModel:
         on) or as two launches with the downsample tensor as the residual."""
         L.check(L.lib().rn_model_set_pair_fusion(self.handle, int(on)), "rn_model_set_pair_fusion")
 
+    def set_stem_exact(self, on: bool) -> None:
+        """fp32: stem in the exact-K form (K = 160, default) or the 4-channel slot form (224)."""
+        L.check(L.lib().rn_model_set_stem_exact(self.handle, int(on)), "rn_model_set_stem_exact")
+
     def set_profiling(self, on: bool) -> None:
         L.check(L.lib().rn_model_set_profiling(self.handle, int(on)), "rn_model_set_profiling")
 

@@ -149,6 +149,35 @@ def conv2d_nhwc_fused(x, w, stride=1, pad=0, scale=None, shift=None, residual=No
     return _down(out, (B, Cout, ho, wo), "nhwc")
 
 
+def conv2d_nhwc_exact(x, w, stride=1, pad=0, scale=None, shift=None, residual=None,
+                      relu_: bool = False) -> np.ndarray:
+    """Small-Cin convolution in the exact-K form: rn_nchw_to_nhwc_pad_dt (physical border) +
+    rn_conv2d_pack_weight_exact + rn_conv2d_nhwc_exact_forward.  NCHW fp32 host arrays."""
+    ctx, lib = get_ctx(), L.lib()
+    B, Cin, H, W = x.shape
+    Cout, _, k, _ = w.shape
+    Hp, Wp = H + 2 * pad, W + 2 * pad
+    ho, wo = conv_output_size(Hp, k, stride, 0), conv_output_size(Wp, k, stride, 0)
+    dx32 = _up(np.asarray(x, dtype=np.float32), "nchw")
+    dx = FloatTensor((B, Hp, Wp, Cin), Device.GPU)
+    L.check(lib.rn_nchw_to_nhwc_pad_dt(ctx.handle, L.RN_DTYPE_F32, dx32.data(), dx.data(), B, Cin,
+                                       H, W, Cin, pad), "rn_nchw_to_nhwc_pad_dt", ctx.handle)
+    dw = _up(w, "nchw")
+    packed = FloatTensor((int(lib.rn_conv2d_packed_weight_numel_exact(Cin, Cout, k)),), Device.GPU)
+    L.check(lib.rn_conv2d_pack_weight_exact(ctx.handle, dw.data(), packed.data(), Cin, Cout, k),
+            "rn_conv2d_pack_weight_exact", ctx.handle)
+    keep = [_up(v, "nchw") if v is not None else None for v in (scale, shift)]
+    dres = _up(residual, "nhwc") if residual is not None else None
+    ep = L.Epilogue(keep[0].data() if keep[0] else None, keep[1].data() if keep[1] else None,
+                    dres.data() if dres else None, int(relu_))
+    out = FloatTensor((B, Cout, ho, wo), Device.GPU)
+    L.check(lib.rn_conv2d_nhwc_exact_forward(ctx.handle, dx.data(), out.data(), packed.data(), k,
+                                             stride, ho, wo, B, Cin, Cout, Hp, Wp, ctypes.byref(ep)),
+            "rn_conv2d_nhwc_exact_forward", ctx.handle)
+    ctx.sync()
+    return _down(out, (B, Cout, ho, wo), "nhwc")
+
+
 # ---------------------------------------------------------------------------
 # bf16 storage (element-type tagged entry points)
 # ---------------------------------------------------------------------------

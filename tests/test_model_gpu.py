@@ -273,3 +273,19 @@ def test_pair_fusion_changes_launches_not_results(model50, finch):
     assert n_plain - n_pair == 4
     assert np.abs(with_pair - without).max() <= 2e-5
     assert np.array_equal(with_pair.argmax(1), without.argmax(1))
+
+
+def test_stem_forms_agree(model50, finch):
+    """The fp32 stem as K = 160 (exact form, default) and as K = 224 (4-channel slots) sum the
+    same 147 products in different orders."""
+    x = R.weights.generate_input(2, seed=88)
+    x[1] = finch[0]
+    for fused in (True, False):
+        a = model50.forward(x, fused=fused)
+        model50.set_stem_exact(False)
+        try:
+            b = model50.forward(x, fused=fused)
+        finally:
+            model50.set_stem_exact(True)
+        assert np.abs(a - b).max() <= 1e-5
+        assert np.array_equal(a.argmax(1), b.argmax(1))

@@ -150,6 +150,28 @@ def test_conv_pair_rejects_what_it_cannot_do():
         ops.conv2d_nhwc_pair(t, w, rnd((1, 32, 9, 9), 3), rnd((32, 32, 1, 1), 4), stride2=3)
 
 
+@pytest.mark.parametrize("case", [
+    (2, 3, 64, 224, 224, 7, 2, 3),   # the stem: K = 147 -> 160
+    (3, 3, 64, 20, 23, 7, 2, 3),     # ragged M, odd width
+    (1, 1, 8, 9, 9, 3, 1, 1),        # one channel, K = 9 -> 32 (one K tile)
+    (2, 4, 72, 12, 10, 5, 1, 2),     # K = 100 -> 128, Cout not a tile multiple
+    (2, 2, 16, 8, 8, 2, 2, 0),       # no padding, K = 8
+])
+def test_exact_small_cin_form(case):
+    """rn_conv2d_nhwc_exact_forward: K = k*k*Cin packed without slot padding, dword gathers
+    from a physically padded image."""
+    B, Cin, Cout, H, W, k, s, p = case
+    seed = 500 + sum(case)
+    x, w = rnd((B, Cin, H, W), seed), rnd((Cout, Cin, k, k), seed + 1)
+    want = O.conv2d(x, w, s, p)
+    assert_close(ops.conv2d_nhwc_exact(x, w, s, p), want, Cin * k * k)
+    g = np.random.default_rng(seed + 2)
+    sc, sh = g.random(Cout, dtype=np.float32) + 0.5, g.standard_normal(Cout, dtype=np.float32)
+    got = ops.conv2d_nhwc_exact(x, w, s, p, sc, sh, None, True)
+    assert_close(got, O.relu_(want * sc[None, :, None, None] + sh[None, :, None, None]),
+                 Cin * k * k + 4)
+
+
 def test_batchnorm_fold_entry_point():
     import ctypes
     from resnet_c_amd import _lib as L
@@ -263,6 +285,27 @@ def test_layout_converters_round_trip():
             ctx.sync()
             got = pad.cpu()._storage.reshape(B, H, W, cpad)
             assert np.array_equal(got[..., :C], x.transpose(0, 2, 3, 1)) and not got[..., C:].any()
+
+
+@pytest.mark.parametrize("case", [(2, 3, 224, 224, 3, 3), (3, 3, 10, 13, 3, 3), (2, 3, 6, 6, 4, 1),
+                                  (1, 1, 5, 5, 1, 2), (2, 2, 8, 8, 4, 0), (1, 3, 7, 9, 8, 2)])
+def test_bordered_nhwc_image_fp32(case):
+    """rn_nchw_to_nhwc_pad_dt(F32): [B,H+2b,W+2b,Cpad] with zero border and zero pad channels
+    (16-byte-store kernel where the image size allows, element kernel otherwise)."""
+    from resnet_c_amd import _lib as L
+    B, C, H, W, cpad, border = case
+    ctx, lib = R.get_ctx(), L.lib()
+    x = rnd((B, C, H, W), 900 + sum(case))
+    src = R.FloatTensor.from_numpy(x, R.Device.GPU)
+    Hp, Wp = H + 2 * border, W + 2 * border
+    dst = R.FloatTensor((B, Hp, Wp, cpad), R.Device.GPU)
+    L.check(lib.rn_memset(ctx.handle, dst.data(), 0xFF, B * Hp * Wp * cpad * 4), "memset", ctx.handle)
+    L.check(lib.rn_nchw_to_nhwc_pad_dt(ctx.handle, L.RN_DTYPE_F32, src.data(), dst.data(), B, C, H, W,
+                                       cpad, border), "pad_dt", ctx.handle)
+    ctx.sync()
+    want = np.zeros((B, Hp, Wp, cpad), dtype=np.float32)
+    want[:, border:border + H, border:border + W, :C] = x.transpose(0, 2, 3, 1)
+    assert np.array_equal(dst.cpu()._storage.reshape(B, Hp, Wp, cpad), want)
 
 
 def test_error_convention_status_not_abort():

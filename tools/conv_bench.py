@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--relu", action="store_true")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--cand", type=int, default=-1, help="time this candidate only")
+    ap.add_argument("--exact", action="store_true", help="small-Cin exact-K form (fp32)")
     a = ap.parse_args()
     B, H, W, Cin, Cout, k, s, p = a.dims
     lib, ctx = L.lib(), R.get_ctx()
@@ -38,8 +39,10 @@ def main():
             h = R.ops.to_bf16_bits(h)
         L.check(lib.rn_memcpy_h2d(ctx.handle, b.ptr, h.ctypes.data, h.nbytes), "h2d", ctx.handle)
         return b
-    x = buf(B * H * W * Cin)
-    wn = int(lib.rn_conv2d_packed_weight_numel_dt(dt, Cin, Cout, k))
+    Hp, Wp = H + 2 * p, W + 2 * p
+    x = buf(B * Hp * Wp * Cin) if a.exact else buf(B * H * W * max(Cin, 4))
+    wn = int(lib.rn_conv2d_packed_weight_numel_exact(Cin, Cout, k)) if a.exact else \
+        int(lib.rn_conv2d_packed_weight_numel_dt(dt, Cin, Cout, k))
     w = buf(wn)
     out = _DeviceBuffer(ctx, B * ho * wo * Cout * es)
     res = buf(B * ho * wo * Cout) if a.residual else None
@@ -54,6 +57,10 @@ def main():
     for cand in (range(0, lib.rn_conv_tile_candidates() + 1) if a.cand < 0 else [a.cand]):
         lib.rn_ctx_set_conv_tile(ctx.handle, cand)
         def run():
+            if a.exact:
+                L.check(lib.rn_conv2d_nhwc_exact_forward(ctx.handle, x.ptr, out.ptr, w.ptr, k, s, ho, wo,
+                                                         B, Cin, Cout, Hp, Wp, ctypes.byref(ep)), "conv", ctx.handle)
+                return
             L.check(lib.rn_conv2d_nhwc_forward_dt(ctx.handle, dt, dt, x.ptr, out.ptr, w.ptr, k, s, p, ho, wo,
                                                   B, Cin, Cout, H, W, ctypes.byref(ep)), "conv", ctx.handle)
         run(); run()

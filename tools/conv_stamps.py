@@ -16,6 +16,7 @@ ap.add_argument("dims", type=int, nargs=8)
 ap.add_argument("--cand", type=int, default=1)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--residual", action="store_true")
+ap.add_argument("--exact", action="store_true", help="small-Cin exact-K form (fp32): dims are the unpadded image")
 ap.add_argument("--soak", type=float, default=1.5, help="seconds of back-to-back launches before the stamped one")
 a = ap.parse_args()
 B, H, W, Cin, Cout, k, s, p = a.dims
@@ -30,7 +31,11 @@ def buf(n):
     if es == 2: h = R.ops.to_bf16_bits(h)
     L.check(lib.rn_memcpy_h2d(ctx.handle, b.ptr, h.ctypes.data, h.nbytes), "h2d", ctx.handle)
     return b
-x = buf(B * H * W * Cin); wn = int(lib.rn_conv2d_packed_weight_numel_dt(dt, Cin, Cout, k)); w = buf(wn)
+if a.exact:
+    Hp, Wp = H + 2 * p, W + 2 * p
+    x = buf(B * Hp * Wp * Cin); wn = int(lib.rn_conv2d_packed_weight_numel_exact(Cin, Cout, k)); w = buf(wn)
+else:
+    x = buf(B * H * W * max(Cin, 4) if Cin < 4 else B * H * W * Cin); wn = int(lib.rn_conv2d_packed_weight_numel_dt(dt, Cin, Cout, k)); w = buf(wn)
 out = _DeviceBuffer(ctx, B * ho * wo * Cout * es); res = buf(B * ho * wo * Cout) if a.residual else None
 sc = R.FloatTensor.from_numpy(np.ones(Cout, np.float32), R.Device.GPU)
 ep = L.Epilogue(sc.data(), sc.data(), res.ptr if res else None, 1)
@@ -38,6 +43,9 @@ nblk = 1 << 16
 st = _DeviceBuffer(ctx, nblk * 128)
 lib.rn_ctx_set_conv_tile(ctx.handle, a.cand)
 def run():
+    if a.exact:
+        L.check(lib.rn_conv2d_nhwc_exact_forward(ctx.handle, x.ptr, out.ptr, w.ptr, k, s, ho, wo, B, Cin, Cout, Hp, Wp, ctypes.byref(ep)), "conv", ctx.handle)
+        return
     L.check(lib.rn_conv2d_nhwc_forward_dt(ctx.handle, dt, dt, x.ptr, out.ptr, w.ptr, k, s, p, ho, wo, B, Cin, Cout, H, W, ctypes.byref(ep)), "conv", ctx.handle)
 run(); run(); ctx.sync()
 import time
