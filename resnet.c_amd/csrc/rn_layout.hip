@@ -230,6 +230,28 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_border_f4_kernel(
     dst[b * n4 + i] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// same, bf16, Cpad = 4: two pixels (16 bytes) per thread; needs an even W + 2b
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_border_bf16_kernel(
+    const float *__restrict__ src, uint4 *__restrict__ dst, uint32_t C, uint32_t H, uint32_t W,
+    uint32_t border, uint32_t Wp, uint32_t n2, uint32_t mul_w, uint32_t shr_w)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;  // pixel pair of one image
+    if (i >= n2) return;
+    const uint64_t b = blockIdx.y;
+    const float *img = src + b * C * H * W;
+    const uint32_t pix = 2 * i;
+    const uint32_t hp = __umulhi(pix, mul_w) >> shr_w;
+    const uint32_t h = hp - border, w0 = pix - hp * Wp - border;  // wrap = out of range
+    typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+    bf16x8_t v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t c = e & 3, w = w0 + (e >> 2);
+        v[e] = (bf16_t)((c < C && h < H && w < W) ? img[(c * H + h) * W + w] : 0.f);
+    }
+    dst[b * n2 + i] = __builtin_bit_cast(uint4, v);
+}
+
 void magic_div(uint32_t d, uint32_t *mul, uint32_t *shr)
 {
     uint32_t lg = 0;
@@ -373,7 +395,20 @@ int rn_nchw_to_nhwc_pad_dt(rn_ctx *ctx, int dtype, const float *src, void *dst, 
     RN_REQUIRE(ctx, Cpad >= C && C >= 1, "Cpad must be >= C >= 1");
     RN_REQUIRE(ctx, H < (1u << 20) && W < (1u << 20) && Cpad < (1u << 20) && border < (1u << 10),
                "dimension too large");
-    if (dtype == RN_DTYPE_BF16) {
+    if (dtype == RN_DTYPE_BF16 && Cpad == 4 && (W + 2 * border) % 2 == 0 &&
+        (H + 2 * border) * (W + 2 * border) < (1ull << 31) &&
+        (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        const uint32_t n2 = (uint32_t)((H + 2 * border) * (W + 2 * border) / 2);
+        uint32_t mw = 0, sw = 0;
+        magic_div((uint32_t)(W + 2 * border), &mw, &sw);
+        for (uint64_t b0 = 0; b0 < B; b0 += 65535) {
+            const uint64_t nb = (B - b0) < 65535 ? (B - b0) : 65535;
+            nchw_to_nhwc4_border_bf16_kernel<<<dim3((n2 + 255) / 256, (unsigned)nb), 256, 0,
+                                               ctx->stream>>>(
+                src + b0 * C * H * W, (uint4 *)dst + b0 * n2, (uint32_t)C, (uint32_t)H,
+                (uint32_t)W, (uint32_t)border, (uint32_t)(W + 2 * border), n2, mw, sw);
+        }
+    } else if (dtype == RN_DTYPE_BF16) {
         nchw_to_nhwc_border_kernel<bf16_t><<<rn_stream_grid(total, 256), 256, 0, ctx->stream>>>(
             src, (bf16_t *)dst, (uint32_t)C, (uint32_t)H, (uint32_t)W, (uint32_t)Cpad,
             (uint32_t)border, total);

@@ -71,6 +71,31 @@ def test_bf16_conv_pair():
     np.testing.assert_allclose(got, ops.bf16_round(want), rtol=2 ** -7, atol=1e-2)
 
 
+@pytest.mark.parametrize("case", [(2, 3, 224, 224, 4, 3), (2, 3, 9, 10, 4, 2), (1, 3, 6, 7, 4, 1),
+                                  (2, 2, 5, 5, 8, 1)])
+def test_bf16_bordered_image(case):
+    """rn_nchw_to_nhwc_pad_dt(BF16): fp32 NCHW -> bf16 [B,H+2b,W+2b,Cpad], RNE, zero border (the
+    two-pixels-per-store kernel for Cpad = 4 and an even padded width, element kernel otherwise)."""
+    from resnet_c_amd import _lib as L
+    from resnet_c_amd.tensor import _DeviceBuffer
+    B, C, H, W, cpad, border = case
+    ctx, lib = R.get_ctx(), L.lib()
+    x = rnd((B, C, H, W), 40 + sum(case))
+    src = R.FloatTensor.from_numpy(x, R.Device.GPU)
+    Hp, Wp = H + 2 * border, W + 2 * border
+    n = B * Hp * Wp * cpad
+    dst = _DeviceBuffer(ctx, n * 2)
+    L.check(lib.rn_memset(ctx.handle, dst.ptr, 0xFF, n * 2), "memset", ctx.handle)
+    L.check(lib.rn_nchw_to_nhwc_pad_dt(ctx.handle, L.RN_DTYPE_BF16, src.data(), dst.ptr, B, C, H, W,
+                                       cpad, border), "pad_dt", ctx.handle)
+    ctx.sync()
+    got = np.empty(n, dtype=np.uint16)
+    L.check(lib.rn_memcpy_d2h(ctx.handle, got.ctypes.data, dst.ptr, got.nbytes), "d2h", ctx.handle)
+    want = np.zeros((B, Hp, Wp, cpad), dtype=np.float32)
+    want[:, border:border + H, border:border + W, :C] = x.transpose(0, 2, 3, 1)
+    assert np.array_equal(got.reshape(B, Hp, Wp, cpad), ops.to_bf16_bits(want).reshape(B, Hp, Wp, cpad))
+
+
 def test_bf16_pools():
     x = rnd((2, 64, 14, 14), 5)
     xb = ops.bf16_round(x)
