@@ -117,7 +117,7 @@ struct Elem<bf16_t> {
     static constexpr int CH = 8;
 };
 
-constexpr int ROW_FLOATS = 32;
+constexpr int ROW_FLOATS = 32;  // LDS row = 128 bytes, addressed as 32 dwords
 
 // Diagnostic time stamps (100 MHz wall clock) of a block's phases; off unless a debug
 // buffer was attached to the context.  Nothing else reads that buffer.
@@ -130,18 +130,6 @@ __device__ __forceinline__ void stamp_cycles(unsigned long long *buf, int slot)
 {
     if (buf && threadIdx.x == 0) buf[(size_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memtime();
 }
-  // LDS row = 128 bytes, addressed as 32 dwords
-
-__device__ __forceinline__ float finish_nores(float v, float sc, float sh, bool has_scale,
-                                              bool has_shift, int relu)
-{
-    if (has_scale) {
-        v = fmaf(v, sc, sh);
-    } else if (has_shift) {
-        v += sh;
-    }
-    return relu ? fmaxf(v, 0.f) : v;
-}
 
 // EPT consecutive output elements of one row: load (residual) / store as one 16-byte access
 template <typename TO>
@@ -149,10 +137,6 @@ struct OutVec;
 template <>
 struct OutVec<float> {
     static constexpr int EPT = 4;
-    static __device__ __forceinline__ u32x4 load_raw(const void *base, size_t idx)
-    {
-        return *reinterpret_cast<const u32x4 *>(static_cast<const float *>(base) + idx);
-    }
     static __device__ __forceinline__ void unpack(const u32x4 &x, float (&v)[4])
     {
 #pragma unroll
@@ -162,11 +146,6 @@ struct OutVec<float> {
     {
         return u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
                      __float_as_uint(v[3])};
-    }
-    static __device__ __forceinline__ void store(void *base, size_t idx, const float (&v)[4])
-    {
-        *reinterpret_cast<float4 *>(static_cast<float *>(base) + idx) =
-            make_float4(v[0], v[1], v[2], v[3]);
     }
     static __device__ __forceinline__ float load1(const void *base, size_t idx)
     {
@@ -180,10 +159,6 @@ struct OutVec<float> {
 template <>
 struct OutVec<bf16_t> {
     static constexpr int EPT = 8;
-    static __device__ __forceinline__ u32x4 load_raw(const void *base, size_t idx)
-    {
-        return *reinterpret_cast<const u32x4 *>(static_cast<const bf16_t *>(base) + idx);
-    }
     static __device__ __forceinline__ void unpack(const u32x4 &r, float (&v)[8])
     {
         const bf16x8 x = __builtin_bit_cast(bf16x8, r);
@@ -196,13 +171,6 @@ struct OutVec<bf16_t> {
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = (bf16_t)v[j];  // round to nearest even
         return __builtin_bit_cast(u32x4, x);
-    }
-    static __device__ __forceinline__ void store(void *base, size_t idx, const float (&v)[8])
-    {
-        bf16x8 x;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = (bf16_t)v[j];  // round to nearest even
-        *reinterpret_cast<bf16x8 *>(static_cast<bf16_t *>(base) + idx) = x;
     }
     static __device__ __forceinline__ float load1(const void *base, size_t idx)
     {

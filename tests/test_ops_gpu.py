@@ -308,6 +308,55 @@ def test_bordered_nhwc_image_fp32(case):
     assert np.array_equal(dst.cpu()._storage.reshape(B, Hp, Wp, cpad), want)
 
 
+def test_empty_inputs_are_no_ops():
+    """Zero-sized work (B = 0, N = 0, no channels out) returns RN_OK without touching the
+    pointers, as a launch with an empty grid would in the reference."""
+    from resnet_c_amd import _lib as L
+    ctx, lib = R.get_ctx(), L.lib()
+    h = ctx.handle
+    assert lib.rn_conv2d_forward(h, None, None, None, 3, 1, 1, 8, 8, 0, 16, 16, 8, 8) == L.RN_OK
+    assert lib.rn_conv2d_nhwc_forward(h, None, None, None, 3, 1, 1, 8, 8, 0, 32, 32, 8, 8, None) == L.RN_OK
+    assert lib.rn_conv2d_nhwc_forward_dt(h, L.RN_DTYPE_BF16, L.RN_DTYPE_BF16, None, None, None, 1, 1, 0,
+                                         4, 4, 0, 64, 64, 4, 4, None) == L.RN_OK
+    assert lib.rn_conv2d_nhwc_exact_forward(h, None, None, None, 7, 2, 112, 112, 0, 3, 64, 230, 230,
+                                            None) == L.RN_OK
+    assert lib.rn_maxpool2d_forward(h, None, None, 3, 2, 1, 4, 4, 0, 8, 8, 8) == L.RN_OK
+    assert lib.rn_avgpool2d_forward(h, None, None, 7, 1, 0, 1, 1, 2, 0, 7, 7) == L.RN_OK
+    assert lib.rn_linear_forward(h, None, None, None, None, 0, 2048, 1000) == L.RN_OK
+    assert lib.rn_batchnorm2d_forward(h, None, None, None, None, None, None, 0, 8, 16) == L.RN_OK
+    assert lib.rn_add_forward(h, None, None, None, 0) == L.RN_OK
+    assert lib.rn_relu_forward(h, None, None, 0) == L.RN_OK
+    assert lib.rn_nchw_to_nhwc(h, None, None, 0, 3, 4, 4) == L.RN_OK
+    assert lib.rn_nchw_to_nhwc_pad_dt(h, L.RN_DTYPE_F32, None, None, 0, 3, 4, 4, 3, 3) == L.RN_OK
+    assert lib.rn_conv2d_pack_weight(h, None, None, 32, 0, 3) == L.RN_OK
+
+
+def test_oversized_tensors_are_refused_before_any_launch():
+    """Index arithmetic in the kernels is 32-bit (Shape::numel() in the reference overflows
+    silently at 2^31, tensor.cuh:28): sizes past that come back as RN_ERR_INVALID.  The
+    pointers are never dereferenced, so small buffers stand in for the huge tensors."""
+    from resnet_c_amd import _lib as L
+    ctx, lib = R.get_ctx(), L.lib()
+    h = ctx.handle
+    a, b, c = (R.FloatTensor((64,), R.Device.GPU) for _ in range(3))
+    big = 1 << 16   # 65536 x 65536 image = 2^32 elements
+    assert lib.rn_conv2d_forward(h, a.data(), b.data(), c.data(), 1, 1, 0, big, big, 1, 1, 1, big,
+                                 big) == L.RN_ERR_INVALID
+    assert lib.rn_conv2d_nhwc_forward(h, a.data(), b.data(), c.data(), 1, 1, 0, big, big, 1, 32, 32,
+                                      big, big, None) == L.RN_ERR_INVALID
+    assert lib.rn_linear_forward(h, a.data(), b.data(), c.data(), None, 1 << 20, 1 << 12,
+                                 1 << 12) == L.RN_ERR_INVALID
+    assert lib.rn_conv2d_nhwc_exact_forward(h, a.data(), b.data(), c.data(), 7, 2, (big - 7) // 2 + 1,
+                                            (big - 7) // 2 + 1, 1, 3, 64, big, big,
+                                            None) == L.RN_ERR_INVALID
+    assert b"2^31" in lib.rn_last_error(h) or b"too large" in lib.rn_last_error(h)
+    # kernel_size 0 / stride 0 are precondition failures, not divisions by zero
+    assert lib.rn_conv2d_forward(h, a.data(), b.data(), c.data(), 0, 1, 0, 4, 4, 1, 4, 4, 4,
+                                 4) == L.RN_ERR_INVALID
+    assert lib.rn_conv2d_forward(h, a.data(), b.data(), c.data(), 1, 0, 0, 4, 4, 1, 4, 4, 4,
+                                 4) == L.RN_ERR_INVALID
+
+
 def test_error_convention_status_not_abort():
     from resnet_c_amd import _lib as L
     ctx, lib = R.get_ctx(), L.lib()
