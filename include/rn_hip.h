@@ -94,6 +94,13 @@ RN_API int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on);
  * candidate i (all candidates give bit-identical results; used by rn_model_tune). */
 RN_API int rn_conv_tile_candidates(void);
 RN_API int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate);
+/* Latency mode: max_splits > 1 lets a contraction whose output tiles cannot fill the chip
+ * (small batches: B = 1 has 8 tiles of 64x64 in layer4's 3x3 convolutions, on 256 CUs) split
+ * its K loop over up to max_splits blocks per tile; partial sums meet in context scratch and
+ * a second kernel adds them in split order and applies the epilogue.  Deterministic, but the
+ * summation order (and so the last bits) differs from the unsplit launch: 0 (default) keeps
+ * results independent of the batch size.  Range 0..64. */
+RN_API int rn_ctx_set_split_k(rn_ctx *ctx, int max_splits);
 /* Diagnostics: device buffer of 16 x uint64 per block that the contraction kernel fills with
  * wall-clock and shader-clock stamps of its phases (tools/conv_stamps.py); NULL (default) = off. */
 RN_API int rn_ctx_set_debug_stamps(rn_ctx *ctx, void *dev_buffer);

@@ -93,6 +93,13 @@ struct GemmParams {
     // 1x1 / padding-0 convolution of the same output geometry (the downsample branch)
     const void *in2;
     int in2_bytes, H2, W2, Cs2, stride2, nk1;
+    // split K (latency mode): work item v = split * total_tiles + tile; split s sums K tiles
+    // [s*kchunk, min((s+1)*kchunk, nk)) and writes its raw fp32 partial tile to
+    // out + s*split_stride bytes; a second kernel adds the partials in order and finishes
+    int ksplit, kchunk;
+    unsigned total_work;  // total_tiles * ksplit
+    unsigned grid_items;  // host only: blocks of a non-persistent launch
+    long long split_stride;
     // exact-K small-Cin form (XK kernels only): K index q = (kh*KW + kw)*Cin + c over a
     // physically padded image; element q of an A row sits q + (q / kc) * kskip floats after
     // the row's first element (kc = KW*Cin, kskip = (W - KW)*Cin), zero weight past kreal
@@ -210,9 +217,21 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
         n0_ = (int)(logical % (unsigned)p.tiles_n) * BN;
         m0_ = (int)(logical / (unsigned)p.tiles_n) * BM;
     };
+    // work item -> tile origin, K range and split index (one item per tile unless K is split)
+    auto work_item = [&](unsigned v, int &m0_, int &n0_, int &kb_, int &ke_, int &s_) {
+        unsigned s = 0;
+        if (p.ksplit > 1) {
+            s = v / total_tiles;
+            v -= s * total_tiles;
+        }
+        tile_origin(v, m0_, n0_);
+        kb_ = (int)s * p.kchunk;
+        ke_ = min(kb_ + p.kchunk, p.nk);
+        s_ = (int)s;
+    };
     unsigned vtile = blockIdx.x;
-    int m0, n0;
-    tile_origin(vtile, m0, n0);
+    int m0, n0, kb, ke, ks_idx;
+    work_item(vtile, m0, n0, kb, ke, ks_idx);
 
     const int t = threadIdx.x;
     const int c = t & 7;    // 16-byte chunk of the 128-byte row this thread stages
@@ -277,7 +296,10 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
     // with scalar arithmetic; the per-row offset only changes with the tap, and the 128-byte
     // segments of one tap are walked through the scalar offset, so a K tile inside a tap
     // costs no vector ALU work at all (vector ALU work competes with the fp32 MFMA stream).
-    auto load_tile = [&](int kt, u32x4 (&xa)[AP], u32x4 (&xb)[BP]) {
+    // first: the K range of a work item may start inside a tap (split K), so its first load
+    // derives the tap offsets whatever the segment
+    auto load_tile = [&](int kt, u32x4 (&xa)[AP], u32x4 (&xb)[BP], auto first_c) {
+        constexpr bool first = decltype(first_c)::value;
         const unsigned s_kt = (unsigned)__builtin_amdgcn_readfirstlane(kt);
         if constexpr (XK) {
             // four dword gathers per chunk: the chunk's K indices may straddle a kernel row
@@ -307,14 +329,14 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
             // second source: one tap, its segments follow the first source's K tiles
             s_cs = (int)s_kt - p.nk1;
             rs = rsrc_a2;
-            if (s_cs == 0) {
+            if (first || s_cs == 0) {
 #pragma unroll
                 for (int j = 0; j < AP; ++j) a_cur[j] = a_off2[DUAL ? j : 0];
             }
         } else {
             const unsigned tap = p.cseg == 1 ? s_kt : (__umulhi(s_kt, p.mul_cs) >> p.shr_cs);
             s_cs = (int)(s_kt - tap * (unsigned)p.cseg);
-            if (s_cs == 0) {
+            if (first || s_cs == 0) {
                 const unsigned ukh = p.KW == 1 ? tap : (__umulhi(tap, p.mul_kw) >> p.shr_kw);
                 const int s_kh = (int)ukh, s_kw = (int)(tap - ukh * (unsigned)p.KW);
                 const int toff = (s_kh * p.W + s_kw) * p.Cs * ES;
@@ -415,7 +437,6 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
     // of every use, which serialised the 8-16 row stores of a tile (stamps: 7-9 us).
     const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
     const bool has_res = p.residual != nullptr;
-    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
         has_res ? const_cast<void *>(p.residual) : p.out, 0, has_res ? p.out_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
     };
 
     stamp(p.stamps, 7);  // block set up, first loads about to be issued
-    load_tile(0, ra, rb);
+    load_tile(kb, ra, rb, std::true_type{});
     for (;;) {
         const int n = n0 + cv * EPT;
         // the residual tile and the channel constants travel while the K loop runs
@@ -467,27 +488,27 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
         }
 
         const unsigned vnext = vtile + gridDim.x;
-        const bool has_next = vnext < total_tiles;
-        int m0n = 0, n0n = 0;
+        const bool has_next = vnext < p.total_work;
+        int m0n = 0, n0n = 0, kbn = 0, ken = 0, ksn = 0;
         if constexpr (sizeof(T) == 4) {
             // fp32 (MFMA-bound): two K tiles per trip so that the LDS buffer of every access is
             // a compile-time offset -- no vector ALU work at all between the MFMAs.  Inside the
             // loop both loads are unconditional (no phi copies of the staging registers); the
             // last one or two tiles are peeled.
-            int kt = 0;
-            while (kt + 2 < p.nk) {
-                load_tile(kt + 1, ra, rb);
+            int kt = kb;
+            while (kt + 2 < ke) {
+                load_tile(kt + 1, ra, rb, std::false_type{});
                 compute_tile(Buf0{});
                 store_tile(Buf1{}, ra, rb);
                 __syncthreads();
-                load_tile(kt + 2, ra, rb);
+                load_tile(kt + 2, ra, rb, std::false_type{});
                 compute_tile(Buf1{});
                 store_tile(Buf0{}, ra, rb);
                 __syncthreads();
                 kt += 2;
             }
-            if (kt + 1 < p.nk) {  // two tiles left: kt in buffer 0, kt + 1 still to fetch
-                load_tile(kt + 1, ra, rb);
+            if (kt + 1 < ke) {  // two tiles left: kt in buffer 0, kt + 1 still to fetch
+                load_tile(kt + 1, ra, rb, std::false_type{});
                 compute_tile(Buf0{});
                 store_tile(Buf1{}, ra, rb);
                 __syncthreads();
@@ -499,19 +520,19 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
         } else {
             // bf16 (latency-bound): the compact loop keeps the register count, and with it the
             // number of resident blocks, where the unrolled form costs 10 % throughput
-            for (int kt = 0; kt < p.nk; ++kt) {
-                const bool more = kt + 1 < p.nk;
-                if (more) load_tile(kt + 1, ra, rb);
-                compute_tile(kt & 1);
-                if (more) store_tile((kt + 1) & 1, ra, rb);
+            for (int kt = kb; kt < ke; ++kt) {
+                const bool more = kt + 1 < ke;
+                if (more) load_tile(kt + 1, ra, rb, std::false_type{});
+                compute_tile((kt - kb) & 1);
+                if (more) store_tile((kt - kb + 1) & 1, ra, rb);
                 __syncthreads();
             }
         }
         // next tile of this block: its first K tile starts travelling before the epilogue
         if (has_next) {
-            tile_origin(vnext, m0n, n0n);
+            work_item(vnext, m0n, n0n, kbn, ken, ksn);
             setup_rows(m0n, n0n);
-            load_tile(0, ra, rb);
+            load_tile(kbn, ra, rb, std::true_type{});
         }
 
         // epilogue.  The accumulators go through LDS (free after the K loop) so that global
@@ -536,6 +557,10 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
     __syncthreads();
     if (vtile == blockIdx.x) stamp(p.stamps, 6);  // ... by every wave
 
+    // output of this work item: the tensor itself, or partial-sum slice ks_idx of the workspace
+    void *const out_base = static_cast<char *>(p.out) + (long long)ks_idx * p.split_stride;
+    const __amdgpu_buffer_rsrc_t rsrc_o =
+        __builtin_amdgcn_make_buffer_rsrc(out_base, 0, p.out_bytes, 0x00020000);
     if (vec) {
         // straight-line: 16-byte LDS read, channel affine, residual, ReLU, 16-byte store per pass
         float sc[EPT], sh[EPT];
@@ -581,7 +606,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
                 y = fmaf(y, has_scale ? p.scale[n + j] : 1.f, has_shift ? p.shift[n + j] : -0.f);
                 if (has_res) y += OutVec<TO>::load1(p.residual, o);
                 y = p.relu ? fmaxf(y, 0.f) : y;
-                OutVec<TO>::store1(p.out, o, y);
+                OutVec<TO>::store1(out_base, o, y);
             }
         }
     }
@@ -595,6 +620,9 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
         vtile = vnext;
         m0 = m0n;
         n0 = n0n;
+        kb = kbn;
+        ke = ken;
+        ks_idx = ksn;
     }
 }
 
@@ -668,6 +696,42 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirectParams p)
     }
 }
 
+// split K, second step: out = epilogue(partial[0] + partial[1] + ... in that order); four
+// consecutive channels per thread (Cout % 4 == 0), the epilogue of conv_gemm_kernel
+struct FinishParams {
+    const float *partial;
+    void *out;
+    const float *scale, *shift;
+    const void *residual;
+    int relu, splits, Cout;
+    uint64_t slice;  // M * Cout
+};
+
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const FinishParams p)
+{
+    const uint64_t n4 = p.slice / 4, gstride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += gstride) {
+        float4 v = *reinterpret_cast<const float4 *>(p.partial + 4 * i);
+        for (int s = 1; s < p.splits; ++s) {
+            const float4 x = *reinterpret_cast<const float4 *>(p.partial + (uint64_t)s * p.slice + 4 * i);
+            v.x += x.x, v.y += x.y, v.z += x.z, v.w += x.w;
+        }
+        const int n = (int)((4 * i) % (uint64_t)p.Cout);
+        float y[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float sc = p.scale ? p.scale[n + j] : 1.f;
+            const float sh = p.shift ? p.shift[n + j] : -0.f;
+            float r = fmaf(y[j], sc, sh);
+            if (p.residual) r += OutVec<TO>::load1(p.residual, 4 * i + j);
+            y[j] = p.relu ? fmaxf(r, 0.f) : r;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) OutVec<TO>::store1(p.out, 4 * i + j, y[j]);
+    }
+}
+
 bool fits_i32(uint64_t v) { return v < (1ull << 31); }
 
 // n / d == umulhi(n, mul) >> shr for 0 <= n < 2^31, d >= 1 (round-up magic number)
@@ -705,7 +769,7 @@ int resident_blocks_per_cu()
 template <typename T, typename TO, int BM, int BN, bool DUAL, bool XK>
 void launch_one(rn_ctx *ctx, GemmParams &p, bool persistent)
 {
-    unsigned grid = p.total_tiles;
+    unsigned grid = p.grid_items;
     if (persistent) {
         const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN, DUAL, XK>();
         if (grid > slots) grid = slots;
@@ -828,6 +892,65 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     const uint64_t total = tiles_m * tiles_n;
     RN_REQUIRE(ctx, fits_i32(total), "too many tiles");
     p.total_tiles = (unsigned)total;
+    p.ksplit = 1;
+    p.kchunk = p.nk;
+    p.total_work = p.total_tiles;
+    p.split_stride = 0;
+
+    // Latency mode (rn_ctx_set_split_k): a launch whose tiles cannot fill the chip splits its
+    // K loop over several blocks; each writes a raw fp32 partial tile to scratch and a second
+    // kernel adds the partials in split order and applies the epilogue.  Deterministic, but
+    // the summation order differs from the unsplit launch, so it is opt-in.
+    if (ctx->split_k > 1 && total < 512 && p.nk >= 8 && Cout % 4 == 0 &&
+        !(second && dt_in == RN_DTYPE_BF16)) {
+        int S = (int)rn_ceil_div(1024, total);
+        if (S > ctx->split_k) S = ctx->split_k;
+        if (S > p.nk / 4) S = p.nk / 4;  // at least four K tiles per block
+        if (S > 1) {
+            const int chunk = (int)rn_ceil_div((uint64_t)p.nk, (uint64_t)S);
+            S = (int)rn_ceil_div((uint64_t)p.nk, (uint64_t)chunk);
+            const uint64_t slice = (uint64_t)p.M * Cout;
+            void *ws = nullptr;
+            RN_TRY(rn_scratch(ctx, 4, (uint64_t)S * slice * sizeof(float), &ws));
+            GemmParams q = p;
+            q.out = ws;
+            q.scale = q.shift = nullptr;
+            q.residual = nullptr;
+            q.relu = 0;
+            q.ksplit = S;
+            q.kchunk = chunk;
+            q.total_work = p.total_tiles * (unsigned)S;
+            q.split_stride = (long long)(slice * sizeof(float));
+            q.out_bytes = (int)(slice * sizeof(float));
+            q.grid_items = q.total_work;
+            if (exact)
+                launch_tiles<float, float, false, true>(ctx, q, BMsel, BNsel, persistent);
+            else if (second)
+                launch_tiles<float, float, true>(ctx, q, BMsel, BNsel, persistent);
+            else if (dt_in == RN_DTYPE_F32)
+                launch_tiles<float, float>(ctx, q, BMsel, BNsel, persistent);
+            else
+                launch_tiles<bf16_t, float>(ctx, q, BMsel, BNsel, persistent);
+            RN_TRY(rn_after_launch(ctx, what));
+            FinishParams f;
+            f.partial = (const float *)ws;
+            f.out = out;
+            f.scale = p.scale;
+            f.shift = p.shift;
+            f.residual = p.residual;
+            f.relu = p.relu;
+            f.splits = S;
+            f.Cout = (int)Cout;
+            f.slice = slice;
+            const unsigned fgrid = rn_stream_grid(slice / 4, 256);
+            if (dt_out == RN_DTYPE_BF16)
+                splitk_finish_kernel<bf16_t><<<fgrid, 256, 0, ctx->stream>>>(f);
+            else
+                splitk_finish_kernel<float><<<fgrid, 256, 0, ctx->stream>>>(f);
+            return rn_after_launch(ctx, what);
+        }
+    }
+    p.grid_items = p.total_tiles;
     if (exact)
         launch_tiles<float, float, false, true>(ctx, p, BMsel, BNsel, persistent);
     else if (second && dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)

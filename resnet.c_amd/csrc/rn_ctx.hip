@@ -36,7 +36,7 @@ int rn_after_launch(rn_ctx *ctx, const char *what)
 
 int rn_scratch(rn_ctx *ctx, int slot, uint64_t bytes, void **ptr)
 {
-    if (slot < 0 || slot >= 4) return rn_set_error(ctx, RN_ERR_INVALID, "bad scratch slot");
+    if (slot < 0 || slot >= 5) return rn_set_error(ctx, RN_ERR_INVALID, "bad scratch slot");
     if (ctx->scratch_bytes[slot] < bytes) {
         // the old block may still be in use by queued kernels
         RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -110,7 +110,7 @@ int rn_ctx_destroy(rn_ctx *ctx)
     if (!ctx) return RN_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -146,6 +146,15 @@ int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate)
 }
 
 int rn_conv_tile_candidates(void) { return 8; }
+
+int rn_ctx_set_split_k(rn_ctx *ctx, int max_splits)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (max_splits < 0 || max_splits > 64)
+        return rn_set_error(ctx, RN_ERR_INVALID, "split_k %d out of range [0, 64]", max_splits);
+    ctx->split_k = max_splits <= 1 ? 0 : max_splits;
+    return RN_OK;
+}
 
 int rn_ctx_set_debug_stamps(rn_ctx *ctx, void *dev_buffer)
 {

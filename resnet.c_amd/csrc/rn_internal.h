@@ -15,11 +15,12 @@ struct rn_ctx {
     int layout;
     int sync_each_op;
     int conv_tile;  // 0 = choose per launch, 1..N = force candidate (tuning)
+    int split_k;    // 0 = never split the K loop; n = up to n partial sums per output (latency mode)
     void *debug_stamps;  // diagnostic phase stamps of the contraction kernel, normally null
     // scratch grown on demand (never inside a graph capture; callers that capture
     // warm up first so the sizes are already settled)
-    void *scratch[4];
-    uint64_t scratch_bytes[4];
+    void *scratch[5];  // 0 batch-norm constants, 1-3 NCHW convolution, 4 split-K partial sums
+    uint64_t scratch_bytes[5];
     char err[512];
 };
 

@@ -289,3 +289,21 @@ def test_stem_forms_agree(model50, finch):
             model50.set_stem_exact(True)
         assert np.abs(a - b).max() <= 1e-5
         assert np.array_equal(a.argmax(1), b.argmax(1))
+
+
+def test_split_k_model_latency_mode(model50, finch):
+    """Whole network at B = 1 with the K loops of under-filled layers split: logits within the
+    reassociation tolerance of the default path, same top-1, deterministic."""
+    ctx = model50.ctx
+    base = model50.forward(finch, fused=True)
+    ctx.set_split_k(16)
+    try:
+        a = model50.forward(finch, fused=True)
+        b = model50.forward(finch, fused=True)
+        ops_mode = model50.forward(finch, fused=False)
+    finally:
+        ctx.set_split_k(0)
+    assert np.array_equal(a, b)
+    assert np.abs(a - base).max() <= 1e-5 and np.abs(ops_mode - base).max() <= 2e-5
+    assert a.argmax(1)[0] == base.argmax(1)[0] == 112
+    assert np.array_equal(model50.forward(finch, fused=True), base)

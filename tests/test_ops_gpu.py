@@ -308,6 +308,40 @@ def test_bordered_nhwc_image_fp32(case):
     assert np.array_equal(dst.cpu()._storage.reshape(B, Hp, Wp, cpad), want)
 
 
+@pytest.mark.parametrize("case", [
+    (1, 512, 512, 7, 7, 3, 1, 1),      # layer4 conv2 at B = 1: 8 tiles, 144 K tiles
+    (2, 1024, 256, 14, 14, 1, 1, 0),   # layer3 conv1
+    (1, 256, 72, 5, 5, 3, 2, 1),       # ragged M and Cout, stride 2
+    (3, 2048, 1000, 1, 1, 1, 1, 0),    # the fc shape
+])
+def test_split_k_latency_mode(case):
+    """rn_ctx_set_split_k: under-filled contractions split their K loop over several blocks;
+    the partial sums are added in split order by a second kernel that also runs the epilogue.
+    Same tolerance as the unsplit kernel, deterministic, and off again afterwards."""
+    B, Cin, Cout, H, W, k, s, p = case
+    seed = 700 + sum(case)
+    x, w = rnd((B, Cin, H, W), seed), rnd((Cout, Cin, k, k), seed + 1)
+    g = np.random.default_rng(seed + 2)
+    sc, sh = g.random(Cout, dtype=np.float32) + 0.5, g.standard_normal(Cout, dtype=np.float32)
+    y = O.conv2d(x, w, s, p)
+    res = rnd(y.shape, seed + 3)
+    want = O.relu_(y * sc[None, :, None, None] + sh[None, :, None, None] + res)
+    ctx = R.get_ctx()
+    plain = ops.conv2d_nhwc_fused(x, w, s, p, sc, sh, res, True)
+    ctx.set_split_k(16)
+    try:
+        got = ops.conv2d_nhwc_fused(x, w, s, p, sc, sh, res, True)
+        again = ops.conv2d_nhwc_fused(x, w, s, p, sc, sh, res, True)
+        raw = ops.conv2d_nhwc_fused(x, w, s, p)   # no epilogue at all
+    finally:
+        ctx.set_split_k(0)
+    assert_close(got, want, Cin * k * k + 4)
+    assert_close(raw, y, Cin * k * k)
+    assert np.array_equal(got, again)
+    assert not np.array_equal(got, plain) or Cin * k * k < 256   # it really took the other path
+    assert np.array_equal(ops.conv2d_nhwc_fused(x, w, s, p, sc, sh, res, True), plain)
+
+
 def test_empty_inputs_are_no_ops():
     """Zero-sized work (B = 0, N = 0, no channels out) returns RN_OK without touching the
     pointers, as a launch with an empty grid would in the reference."""
