@@ -20,20 +20,22 @@ namespace {
 
 constexpr int kBlock = 256;
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(kBlock) void relu_kernel(const float *inp,
                                                       float *out, uint64_t n4,
                                                       uint64_t n)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    const float4 *in4 = reinterpret_cast<const float4 *>(inp);
-    float4 *out4 = reinterpret_cast<float4 *>(out);
+    const f32x4 *in4 = reinterpret_cast<const f32x4 *>(inp);
+    f32x4 *out4 = reinterpret_cast<f32x4 *>(out);
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        float4 v = in4[i];
+        f32x4 v = __builtin_nontemporal_load(&in4[i]);  // streamed once: keep it out of L2
         v.x = fmaxf(v.x, 0.f);
         v.y = fmaxf(v.y, 0.f);
         v.z = fmaxf(v.z, 0.f);
         v.w = fmaxf(v.w, 0.f);
-        out4[i] = v;
+        __builtin_nontemporal_store(v, &out4[i]);
     }
     // tail (N % 4) handled by the first threads of block 0
     const uint64_t t = n4 * 4 + threadIdx.x;
@@ -54,12 +56,12 @@ __global__ __launch_bounds__(kBlock) void add_kernel(const float *a,
                                                      uint64_t n)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    const float4 *a4 = reinterpret_cast<const float4 *>(a);
-    const float4 *b4 = reinterpret_cast<const float4 *>(b);
-    float4 *out4 = reinterpret_cast<float4 *>(out);
+    const f32x4 *a4 = reinterpret_cast<const f32x4 *>(a);
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(b);
+    f32x4 *out4 = reinterpret_cast<f32x4 *>(out);
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += stride) {
-        const float4 x = a4[i], y = b4[i];
-        out4[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        const f32x4 x = __builtin_nontemporal_load(&a4[i]), y = __builtin_nontemporal_load(&b4[i]);
+        __builtin_nontemporal_store(x + y, &out4[i]);
     }
     const uint64_t t = n4 * 4 + threadIdx.x;
     if (blockIdx.x == 0 && t < n) out[t] = a[t] + b[t];
@@ -130,15 +132,15 @@ __global__ __launch_bounds__(kBlock) void bn_nchw_vec_kernel(const float *inp, f
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     for (uint32_t plane = wave; plane < planes; plane += nwaves) {
         const BnParams p = bn_load(params + kBnStride * (uint64_t)(plane % C));
-        const float4 *in4 = reinterpret_cast<const float4 *>(inp) + (uint64_t)plane * n4;
-        float4 *out4 = reinterpret_cast<float4 *>(out) + (uint64_t)plane * n4;
+        const f32x4 *in4 = reinterpret_cast<const f32x4 *>(inp) + (uint64_t)plane * n4;
+        f32x4 *out4 = reinterpret_cast<f32x4 *>(out) + (uint64_t)plane * n4;
         for (uint32_t i = lane; i < n4; i += 64) {
-            float4 v = in4[i];
+            f32x4 v = __builtin_nontemporal_load(&in4[i]);  // streamed once: keep it out of L2
             v.x = bn_apply_reg(v.x, p);
             v.y = bn_apply_reg(v.y, p);
             v.z = bn_apply_reg(v.z, p);
             v.w = bn_apply_reg(v.w, p);
-            out4[i] = v;
+            __builtin_nontemporal_store(v, &out4[i]);
         }
     }
 }
@@ -153,8 +155,8 @@ __global__ __launch_bounds__(kBlock) void bn_nhwc_vec_kernel(const float *inp, f
                                                              uint64_t total4, uint32_t c4n)
 {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    const float4 *in4 = reinterpret_cast<const float4 *>(inp);
-    float4 *out4 = reinterpret_cast<float4 *>(out);
+    const f32x4 *in4 = reinterpret_cast<const f32x4 *>(inp);
+    f32x4 *out4 = reinterpret_cast<f32x4 *>(out);
     const uint64_t first = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     BnParams p0, p1, p2, p3;
     if (kFixed) {
@@ -168,12 +170,12 @@ __global__ __launch_bounds__(kBlock) void bn_nhwc_vec_kernel(const float *inp, f
             p0 = bn_load(p), p1 = bn_load(p + kBnStride), p2 = bn_load(p + 2 * kBnStride),
             p3 = bn_load(p + 3 * kBnStride);
         }
-        float4 v = in4[i];
+        f32x4 v = __builtin_nontemporal_load(&in4[i]);
         v.x = bn_apply_reg(v.x, p0);
         v.y = bn_apply_reg(v.y, p1);
         v.z = bn_apply_reg(v.z, p2);
         v.w = bn_apply_reg(v.w, p3);
-        out4[i] = v;
+        __builtin_nontemporal_store(v, &out4[i]);
     }
 }
 

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(kBlock) void pool_nhwc_vec_kernel(
             acc.z = acc.z / kf / kf;
             acc.w = acc.w / kf / kf;
         }
-        out4[i64] = acc;
+        // written once, read by the next op from HBM: a streaming store keeps the input rows,
+        // which neighbouring windows re-read, in the cache
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f32x4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<f32x4 *>(&out4[i64]));
     }
 }
 
