@@ -10,10 +10,32 @@
 #include <vector>
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int BK = 32;
+
+// -DLAB_BF16: the same byte layout read as bf16 (a 128-byte row = 64 elements, one
+// ds_read_b128 = one operand of v_mfma_f32_32x32x16_bf16): K below is then in units of two
+// bf16, and every K tile is 512 MFMA cycles per wave instead of 4096.
+typedef __bf16 lab_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void lab_mfma(f32x16 &acc, const float4 &a, const float4 &b)
+{
+#ifdef LAB_BF16
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(lab_bf16x8, a), __builtin_bit_cast(lab_bf16x8, b), acc, 0, 0, 0);
+#else
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+#endif
+}
+#ifdef LAB_BF16
+constexpr double kFlopScale = 2.0;
+#else
+constexpr double kFlopScale = 1.0;
+#endif
 
 enum { NO_GLOBAL = 1, NO_STAGE = 2, NO_LDSREAD = 4, PRIO = 8, NO_BARRIER = 16, SAME_TILE = 32, DEEP = 64 };
 
@@ -102,10 +124,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_kernel(const float *A, const fl
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].x, b[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].y, b[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].z, b[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi].w, b[ni].w, acc[mi][ni], 0, 0, 0);
+                    lab_mfma(acc[mi][ni], a[mi], b[ni]);
                 }
         }
         if (LAB & PRIO) __builtin_amdgcn_s_setprio(0);
@@ -441,10 +460,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const float *A, const flo
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].x, xb[ni].x, acc[mi][ni], 0, 0, 0);
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].y, xb[ni].y, acc[mi][ni], 0, 0, 0);
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].z, xb[ni].z, acc[mi][ni], 0, 0, 0);
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mi].w, xb[ni].w, acc[mi][ni], 0, 0, 0);
+                lab_mfma(acc[mi][ni], xa[mi], xb[ni]);
             }
     };
     // prologue: S-1 tiles in flight
@@ -455,9 +471,17 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const float *A, const flo
     for (int i = 0; i < nk; ++i) {
         // retire this wave's pieces of tile i (younger tiles may stay in flight)
         const int younger = min(S - 2, nk - 1 - i);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPIECE) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define LAB_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((n) * NPIECE > 63 ? 63 : (n) * NPIECE) : "memory")
+        switch (younger) {
+        case 0: LAB_WAIT(0); break;
+        case 1: LAB_WAIT(1); break;
+        case 2: LAB_WAIT(2); break;
+        case 3: LAB_WAIT(3); break;
+        case 4: LAB_WAIT(4); break;
+        case 5: LAB_WAIT(5); break;
+        default: LAB_WAIT(6); break;
+        }
+#undef LAB_WAIT
         asm volatile("s_barrier" ::: "memory");
         // stage (i-1)%S is free now (everyone finished tile i-1): refill it with tile i+S-1
         if (i + S - 1 < nk) dma_tile(i + S - 1, st == 0 ? S - 1 : st - 1);
@@ -526,7 +550,7 @@ float run_dma(const float *A, const float *B, float *C, int M, int N, int K, int
     hipEventElapsedTime(&ms, e0, e1);
     ms /= reps;
     printf("  DMA%s BM=%d BN=%d S=%d pin=%d lds=%zuK : %.3f ms  %.1f TF  (%s)\n", SAME ? " sametile" : "", BM, BN, S, PIN, lds_bytes / 1024, ms,
-           2.0 * M * N * K / ms / 1e9, hipGetErrorString(hipGetLastError()));
+           kFlopScale * 2.0 * M * N * K / ms / 1e9, hipGetErrorString(hipGetLastError()));
     return ms;
 }
 
@@ -559,10 +583,54 @@ float run(const float *A, const float *B, float *C, int M, int N, int K, int rep
     printf("  %sBM=%d BN=%d WPS=%d LAB=%2d%s%s%s%s%s%s : %.3f ms  %.1f TF\n", dyn ? "[1 block/CU] " : "", BM, BN, WPS, LAB, (LAB & DEEP) ? " deep" : (LAB & SAME_TILE) ? " sametile" : "",
            (LAB & NO_GLOBAL) ? " -global" : "", (LAB & NO_STAGE) ? " -stage" : "",
            (LAB & NO_LDSREAD) ? " -ldsread" : "", (LAB & PRIO) ? " +prio" : "",
-           (LAB & NO_BARRIER) ? " -barrier" : "", ms, 2.0 * M * N * K / ms / 1e9);
+           (LAB & NO_BARRIER) ? " -barrier" : "", ms, kFlopScale * 2.0 * M * N * K / ms / 1e9);
     return ms;
 }
 
+#ifdef LAB_BF16
+int main()
+{
+    // layer3 3x3 conv (M = 50176, N = 256, K = 2304 bf16) as a plain GEMM; K in float units
+    const int M = 50176, N = 256, K = 1152;
+    float *A, *B, *C, *C2;
+    hipMalloc(&A, (size_t)M * K * 4);
+    hipMalloc(&B, (size_t)N * K * 4);
+    hipMalloc(&C, (size_t)M * N * 4);
+    hipMalloc(&C2, (size_t)M * N * 4);
+    std::vector<unsigned short> h((size_t)M * K * 2);
+    for (auto &v : h) {  // bf16 bit patterns of values in [-1, 1)
+        const float f = (float)rand() / RAND_MAX * 2.f - 1.f;
+        unsigned u;
+        memcpy(&u, &f, 4);
+        v = (unsigned short)(u >> 16);
+    }
+    hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
+    hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+    printf("bf16: M=%d N=%d K=%d  (%.1f GFLOP)\n", M, N, 2 * K, 4.0 * M * N * K / 1e9);
+    const int R = 20;
+    run<128, 128, 0, 2>(A, B, C, M, N, K, R);
+    run<128, 64, 0, 3>(A, B, C2, M, N, K, R);
+    run<64, 64, 0, 4>(A, B, C2, M, N, K, R);
+    run<128, 128, NO_GLOBAL, 2>(A, B, C2, M, N, K, R);
+    run<128, 128, NO_GLOBAL | NO_STAGE, 2>(A, B, C2, M, N, K, R);
+    run<128, 128, NO_GLOBAL | NO_STAGE | NO_LDSREAD | NO_BARRIER, 2>(A, B, C2, M, N, K, R);
+    run_dma<128, 128, 2, 0>(A, B, C2, M, N, K, R);
+    printf("    max|dma - base| = %g\n", check(C2, C, (size_t)M * N));
+    run_dma<128, 128, 3, 0>(A, B, C2, M, N, K, R);
+    printf("    max|dma - base| = %g\n", check(C2, C, (size_t)M * N));
+    run_dma<128, 128, 4, 0>(A, B, C2, M, N, K, R);
+    run_dma<128, 128, 3, 1>(A, B, C2, M, N, K, R);
+    run_dma<128, 64, 3, 0>(A, B, C2, M, N, K, R);
+    run_dma<128, 64, 4, 0>(A, B, C2, M, N, K, R);
+    run_dma<128, 64, 6, 0>(A, B, C2, M, N, K, R);
+    run_dma<64, 64, 3, 0>(A, B, C2, M, N, K, R);
+    run_dma<64, 64, 4, 0>(A, B, C2, M, N, K, R);
+    run_dma<64, 64, 6, 0>(A, B, C2, M, N, K, R);
+    run_dma<64, 64, 8, 0>(A, B, C2, M, N, K, R);
+    printf("    max|dma - base| = %g\n", check(C2, C, (size_t)M * N));
+    return 0;
+}
+#else
 int main()
 {
     const int M = 200704, N = 128, K = 1152;  // layer2 3x3 conv as a plain GEMM
@@ -636,3 +704,4 @@ int main()
     run<64, 64, 0, 4>(A, B, C, M, N, K, R);
     return 0;
 }
+#endif
