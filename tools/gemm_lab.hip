@@ -377,6 +377,155 @@ float run_ws(const float *A, const float *B, float *C, int M, int N, int K, int 
 
 
 // ---------------------------------------------------------------------------------
+// B-direct variant: only the A operand goes through LDS; every wave fetches its B operand
+// (the weights: small, L2-resident, K-contiguous rows) from global memory straight into
+// MFMA-layout registers -- lane (li, lh) of k-step ks needs the 16 bytes at row n = li,
+// byte 128*kt + 16*(2*ks + lh), which is exactly one buffer_load_dwordx4.  Halves the LDS
+// bytes written and read per MFMA; B fragments of tile kt+1 travel while tile kt is
+// multiplied (two register sets, loop unrolled by two).
+template <int BM, int BN, int WPS>
+__global__ __launch_bounds__(256, WPS) void gemm_bdirect_kernel(const float *A, const float *B, float *C,
+                                                                int M, int N, int K, int tiles_n)
+{
+    constexpr int AP = BM / 32, MI = BM / 64, NI = BN / 64;
+    constexpr int STAGE = BM * BK;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(2*STAGE, BM*BN) floats
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_n = (int)(logical % (unsigned)tiles_n), tile_m = (int)(logical / (unsigned)tiles_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int t = threadIdx.x, c = t & 7, r0 = t >> 3;
+    const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(A), 0, M * K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(B), 0, N * K * 4, 0x00020000);
+    const int lane = t & 63, wave = t >> 6, wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int sw = (li >> 1) & 7;
+    int a_off[AP], b_off[NI];
+#pragma unroll
+    for (int j = 0; j < AP; ++j) a_off[j] = ((m0 + r0 + 32 * j) * K + c * 4) * 4;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#ifdef LAB_BFRAG
+        // B re-packed in fragment order: [32-row group][K tile][k-step][lane] x 16 bytes, so a
+        // wave's fragment load is one contiguous KiB
+        b_off[ni] = (((n0 + wc * (BN / 2) + ni * 32) / 32) * (K / BK) * 4 * 64 + lane) * 16;
+#else
+        b_off[ni] = ((n0 + wc * (BN / 2) + ni * 32 + li) * K + lh * 4) * 4;
+#endif
+    }
+    u32x4 ra[AP];
+    u32x4 fb0[4][NI], fb1[4][NI];
+    auto load_a = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < AP; ++j) ra[j] = __builtin_amdgcn_raw_buffer_load_b128(ra_, a_off[j], kt * 128, 0);
+    };
+    auto load_b = [&](int kt, u32x4 (&fb)[4][NI]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#ifdef LAB_BFRAG
+                fb[ks][ni] = __builtin_amdgcn_raw_buffer_load_b128(rb_, b_off[ni], (kt * 4 + ks) * 1024, 0);
+#else
+                fb[ks][ni] = __builtin_amdgcn_raw_buffer_load_b128(rb_, b_off[ni], kt * 128 + ks * 32, 0);
+#endif
+    };
+    auto store_a = [&](int buf) {
+        float *As = lds + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < AP; ++j) {
+            const int row = r0 + 32 * j, pc = c ^ ((row >> 1) & 7);
+            *reinterpret_cast<u32x4 *>(As + row * BK + pc * 4) = ra[j];
+        }
+    };
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+    auto compute = [&](int buf, const u32x4 (&fb)[4][NI]) {
+        const float *As = lds + buf * STAGE + (wr * (BM / 2) + li) * BK;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int pc = ((2 * ks + lh) ^ sw) * 4;
+            float4 a[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const float4 *>(As + mi * 32 * BK + pc);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float4 b = make_float4(__uint_as_float(fb[ks][ni].x), __uint_as_float(fb[ks][ni].y),
+                                                 __uint_as_float(fb[ks][ni].z), __uint_as_float(fb[ks][ni].w));
+                    lab_mfma(acc[mi][ni], a[mi], b);
+                }
+        }
+    };
+    const int nk = K / BK;  // even in every shape the lab runs
+    load_a(0);
+    load_b(0, fb0);
+    store_a(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        load_a(kt + 1);  // kt + 1 < nk because nk is even
+        load_b(kt + 1, fb1);
+        compute(0, fb0);
+        store_a(1);
+        __syncthreads();
+        if (kt + 2 < nk) {
+            load_a(kt + 2);
+            load_b(kt + 2, fb0);
+        }
+        compute(1, fb1);
+        if (kt + 2 < nk) store_a(0);
+        __syncthreads();
+    }
+    float *Cs = lds;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            float *dst = Cs + (wr * (BM / 2) + mi * 32 + 4 * lh) * BN + wc * (BN / 2) + ni * 32 + li;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[mi][ni][e];
+        }
+    __syncthreads();
+    constexpr int C4 = BN / 4, RPP = 256 / C4, PASSES = BM / RPP;
+    const int c4 = t % C4, rr = t / C4;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int row = rr + ps * RPP;
+        const float4 v = *reinterpret_cast<const float4 *>(lds + row * BN + c4 * 4);
+        *reinterpret_cast<float4 *>(C + (size_t)(m0 + row) * N + n0 + c4 * 4) = v;
+    }
+}
+
+template <int BM, int BN, int WPS>
+float run_bdirect(const float *A, const float *B, float *C, int M, int N, int K, int reps)
+{
+    const int tn = N / BN, tm = M / BM;
+    size_t lds_bytes = (size_t)2 * BM * BK * 4;
+    if (lds_bytes < (size_t)BM * BN * 4) lds_bytes = (size_t)BM * BN * 4;
+    hipFuncSetAttribute((const void *)gemm_bdirect_kernel<BM, BN, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) gemm_bdirect_kernel<BM, BN, WPS><<<tm * tn, 256, lds_bytes>>>(A, B, C, M, N, K, tn);
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) gemm_bdirect_kernel<BM, BN, WPS><<<tm * tn, 256, lds_bytes>>>(A, B, C, M, N, K, tn);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("  B-direct BM=%d BN=%d WPS=%d lds=%zuK : %.3f ms  %.1f TF  (%s)\n", BM, BN, WPS, lds_bytes / 1024, ms,
+           kFlopScale * 2.0 * M * N * K / ms / 1e9, hipGetErrorString(hipGetLastError()));
+    return ms;
+}
+
+// ---------------------------------------------------------------------------------
 // LDS-DMA variant: operands go global -> LDS with global_load_lds (16 B per lane,
 // 1 KiB = 8 rows x 128 B per wave instruction, swizzle applied on the SOURCE address),
 // no VGPR staging and no ds_write.  S-stage ring, tiles t+1 .. t+S-1 in flight while
@@ -607,6 +756,25 @@ int main()
     hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
     hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
     printf("bf16: M=%d N=%d K=%d  (%.1f GFLOP)\n", M, N, 2 * K, 4.0 * M * N * K / 1e9);
+    float *Bf = B;
+#ifdef LAB_BFRAG
+    {
+        const float *hb = reinterpret_cast<const float *>(h.data());  // B = first N rows of h
+        std::vector<float> f((size_t)N * K);
+        const int nkt = K / BK;
+        for (int g = 0; g < N / 32; ++g)
+            for (int kt = 0; kt < nkt; ++kt)
+                for (int ks = 0; ks < 4; ++ks)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int li = lane & 31, lh = lane >> 5;
+                        const float *src = hb + (size_t)(g * 32 + li) * K + kt * BK + (2 * ks + lh) * 4;
+                        float *dst = f.data() + ((((size_t)g * nkt + kt) * 4 + ks) * 64 + lane) * 4;
+                        for (int e = 0; e < 4; ++e) dst[e] = src[e];
+                    }
+        hipMalloc(&Bf, (size_t)N * K * 4);
+        hipMemcpy(Bf, f.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+    }
+#endif
     const int R = 20;
     run<128, 128, 0, 2>(A, B, C, M, N, K, R);
     run<128, 64, 0, 3>(A, B, C2, M, N, K, R);
@@ -614,6 +782,15 @@ int main()
     run<128, 128, NO_GLOBAL, 2>(A, B, C2, M, N, K, R);
     run<128, 128, NO_GLOBAL | NO_STAGE, 2>(A, B, C2, M, N, K, R);
     run<128, 128, NO_GLOBAL | NO_STAGE | NO_LDSREAD | NO_BARRIER, 2>(A, B, C2, M, N, K, R);
+    run_bdirect<128, 128, 2>(A, Bf, C2, M, N, K, R);
+    printf("    max|bdirect - base| = %g\n", check(C2, C, (size_t)M * N));
+    run_bdirect<128, 64, 2>(A, Bf, C2, M, N, K, R);
+    run_bdirect<128, 64, 3>(A, Bf, C2, M, N, K, R);
+    printf("    max|bdirect - base| = %g\n", check(C2, C, (size_t)M * N));
+    run_bdirect<64, 64, 3>(A, Bf, C2, M, N, K, R);
+    run_bdirect<64, 64, 4>(A, Bf, C2, M, N, K, R);
+    run_bdirect<64, 128, 2>(A, Bf, C2, M, N, K, R);
+    run_bdirect<64, 128, 3>(A, Bf, C2, M, N, K, R);
     run_dma<128, 128, 2, 0>(A, B, C2, M, N, K, R);
     printf("    max|dma - base| = %g\n", check(C2, C, (size_t)M * N));
     run_dma<128, 128, 3, 0>(A, B, C2, M, N, K, R);
