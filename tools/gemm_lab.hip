@@ -807,6 +807,38 @@ int main()
     printf("    max|dma - base| = %g\n", check(C2, C, (size_t)M * N));
     return 0;
 }
+#elif defined(LAB_F32_64)
+int main()
+{
+    // the 64x64 tile (the tuner's usual pick) on the layer3 3x3 shape with M cut to an exact
+    // 12 tiles per CU (no tail), fp32: which part of the loop keeps the matrix pipe idle?
+    const int M = 49152, N = 256, K = 2304;
+    float *A, *B, *C;
+    hipMalloc(&A, (size_t)M * K * 4);
+    hipMalloc(&B, (size_t)N * K * 4);
+    hipMalloc(&C, (size_t)M * N * 4);
+    std::vector<float> h((size_t)M * K);
+    for (auto &v : h) v = (float)rand() / RAND_MAX * 2.f - 1.f;
+    hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice);
+    hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+    printf("fp32: M=%d N=%d K=%d  (%.1f GFLOP)\n", M, N, K, 2.0 * M * N * K / 1e9);
+    const int R = 10;
+    run<64, 64, 0, 4>(A, B, C, M, N, K, R);
+    run<64, 64, PRIO, 4>(A, B, C, M, N, K, R);
+    run<64, 64, NO_GLOBAL, 4>(A, B, C, M, N, K, R);
+    run<64, 64, NO_GLOBAL | NO_STAGE, 4>(A, B, C, M, N, K, R);
+    run<64, 64, NO_GLOBAL | NO_STAGE | NO_BARRIER, 4>(A, B, C, M, N, K, R);
+    run<64, 64, NO_GLOBAL | NO_STAGE | NO_LDSREAD, 4>(A, B, C, M, N, K, R);
+    run<64, 64, NO_GLOBAL | NO_STAGE | NO_LDSREAD | NO_BARRIER, 4>(A, B, C, M, N, K, R);
+    run<64, 64, NO_BARRIER, 4>(A, B, C, M, N, K, R);
+    run<64, 64, NO_LDSREAD, 4>(A, B, C, M, N, K, R);
+    run<64, 64, SAME_TILE, 4>(A, B, C, M, N, K, R);
+    run<128, 128, 0, 2>(A, B, C, M, N, K, R);
+    run<128, 128, NO_GLOBAL | NO_STAGE | NO_LDSREAD | NO_BARRIER, 2>(A, B, C, M, N, K, R);
+    run<128, 64, 0, 3>(A, B, C, M, N, K, R);
+    run<128, 64, NO_GLOBAL | NO_STAGE | NO_LDSREAD | NO_BARRIER, 3>(A, B, C, M, N, K, R);
+    return 0;
+}
 #else
 int main()
 {
