@@ -12,11 +12,11 @@ import resnet_c_amd as R
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "veneer_smoke")
+def _build(tmp_path, name="veneer_smoke"):
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(R._lib.LIB_PATH)
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", f"-I{ROOT}/include",
-                    f"{ROOT}/examples/veneer_smoke.cpp", f"-L{libdir}", "-lrn_hip",
+                    f"{ROOT}/examples/{name}.cpp", f"-L{libdir}", "-lrn_hip",
                     f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
                    check=True, capture_output=True, text=True)
     return exe
@@ -24,6 +24,7 @@ def _build(tmp_path):
 
 def test_veneer_compiles_with_a_plain_host_compiler(tmp_path):
     assert os.path.exists(_build(tmp_path))
+    assert os.path.exists(_build(tmp_path, "resnet_veneer"))
 
 
 @pytest.mark.gpu
@@ -43,3 +44,29 @@ def test_veneer_runs_and_matches_oracle(tmp_path):
     y = O.relu_(O.batchnorm2d_(y, ones, 0.5 * ones, zeros, ones))
     y = O.add_(y, x)
     assert abs(float(m.group(1)) - float(y.astype(np.float64).sum())) < 1e-2
+
+
+@pytest.mark.gpu
+def test_whole_network_through_the_veneer(tmp_path, state50, finch, golden_dir):
+    """examples/resnet_veneer.cpp: ResNet-50 built from the reference-named C++ classes, loading
+    weights_bin/<key> files, one veneer call (= one C-ABI call, NCHW, synchronous) per reference
+    op.  Same logits as the reference module's goldens, same 'max index is N' line."""
+    exe = _build(tmp_path, "resnet_veneer")
+    os.mkdir(tmp_path / "weights_bin")
+    R.weights.save_weights_bin(state50, str(tmp_path / "weights_bin"))
+    x = np.concatenate([finch, R.weights.generate_input(1, seed=7)[:1]]).astype(np.float32)
+    x.tofile(tmp_path / "input.bin")
+    r = subprocess.run([exe, "50", "input.bin", "logits.bin"], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(tmp_path / "logits.bin", dtype=np.float32).reshape(2, 1000)
+    want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
+    assert np.abs(got[:1] - want).max() <= 1e-4
+    lines = [l for l in r.stdout.splitlines() if l.startswith("max index is")]
+    assert lines == [f"max index is {int(got[0].argmax())}", f"max index is {int(got[1].argmax())}"]
+    assert int(got[0].argmax()) == 112
+    m = R.NativeModel("resnet50", state=state50)
+    try:
+        assert np.abs(m.forward(x, fused=False) - got).max() <= 1e-5
+    finally:
+        m.close()
