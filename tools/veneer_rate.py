@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Throughput of the literal drop-in route: the reference-shaped graph (createResnet /
+resnetForward), one C-ABI call per reference op on NCHW tensors, against the model driver.
+
+    python tools/veneer_rate.py [--batch 64] [--steps 5]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import resnet_c_amd as R
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+state = R.weights.generate_state("resnet50", 0)
+x_host = R.weights.generate_input(a.batch, 0)
+ctx = R.get_ctx()
+x = R.FloatTensor.from_numpy(x_host, R.Device.GPU)
+m = R.createResnet("resnet50", state)
+for sync in (True, False):
+    ctx.set_sync_each_op(sync)
+    for _ in range(2):
+        out = R.resnetForward(m, x)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = R.resnetForward(m, x)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(f"NCHW op-by-op graph, sync after each op = {sync}: {dt*1e3:8.2f} ms/forward  {a.batch/dt:8.1f} img/s")
+ctx.set_sync_each_op(False)
+nm = R.NativeModel("resnet50", state=state)
+lg = R.FloatTensor((a.batch, 1000), R.Device.GPU)
+for fused in (False, True):
+    nm.tune(x.data(), a.batch, lg.data(), fused)
+    for _ in range(5):
+        nm.forward_ptr(x.data(), a.batch, lg.data(), fused)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        nm.forward_ptr(x.data(), a.batch, lg.data(), fused)
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(f"model driver (NHWC arenas), fused = {fused}: {dt*1e3:8.2f} ms/forward  {a.batch/dt:8.1f} img/s")
