@@ -863,7 +863,11 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     // least (rounds * tile area / relative tile efficiency), i.e. the least padded,
     // best balanced cover of the 256 CUs.  rn_model_tune measures instead of guessing.
     static const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    static const double cand_eff[4] = {0.84, 0.95, 0.96, 1.00};  // measured, 3x3 and 1x1 at B=256
+    // relative efficiency of a full tile, measured on 3x3 and 1x1 layers at B=256: fp32 is
+    // bound by the matrix pipe and likes many small tiles (occupancy, tails); bf16 is bound by
+    // operand traffic per MFMA and likes large ones
+    static const double eff_f32[4] = {0.84, 0.95, 0.96, 1.00}, eff_bf16[4] = {1.00, 0.92, 0.95, 0.80};
+    const double *cand_eff = dt_in == RN_DTYPE_BF16 ? eff_bf16 : eff_f32;
     int BMsel = 128, BNsel = 128;
     bool persistent;
     if (ctx->conv_tile >= 1 && ctx->conv_tile <= 8) {
