@@ -100,6 +100,15 @@ struct GemmParams {
     unsigned total_work;  // total_tiles * ksplit
     unsigned grid_items;  // host only: blocks of a non-persistent launch
     long long split_stride;
+    // chunked K sum (CHUNK kernels only): every output of the layer is ((c0 + c1) + c2) + ...
+    // with c_i the sum over K tiles [i*chunk_L, (i+1)*chunk_L).  Tiles below full_tiles fold the
+    // chunks in registers; the last tail_tiles logical tiles are cut into (tile, chunk) pieces
+    // that write their raw chunk sum to ws + chunk*ws_stride (same [M][Cout] addressing as the
+    // output) -- a second kernel adds them in the same order and runs the epilogue.
+    int chunk_L;
+    unsigned full_tiles, tail_tiles;
+    void *ws;
+    long long ws_stride;
     // exact-K small-Cin form (XK kernels only): K index q = (kh*KW + kw)*Cin + c over a
     // physically padded image; element q of an A row sits q + (q / kc) * kskip floats after
     // the row's first element (kc = KW*Cin, kskip = (W - KW)*Cin), zero weight past kreal
@@ -192,7 +201,8 @@ struct OutVec<bf16_t> {
 // T: element type of activations and weights; TO: element type of the output (and residual)
 // DUAL: the K loop continues through a second (input, weight-row tail) pair, see GemmParams
 // XK: exact-K small-Cin form (the 7x7x3 stem as K = 147 -> 160 instead of 224), fp32 only
-template <typename T, typename TO, int BM, int BN, bool DUAL = false, bool XK = false>
+// CHUNK: chunked K sum with the tail tiles cut into pieces, fp32 only (see GemmParams)
+template <typename T, typename TO, int BM, int BN, bool DUAL = false, bool XK = false, bool CHUNK = false>
 __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 ? 3 : 2)) void conv_gemm_kernel(const GemmParams p)
 {
     constexpr int CH = Elem<T>::CH, ES = (int)sizeof(T);
@@ -209,16 +219,32 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
     // than the tile count: the next tile's operands are fetched during this tile's epilogue).
     __builtin_amdgcn_s_setprio(3);
     stamp(p.stamps, 0);
-    const unsigned total_tiles = p.total_tiles;
-    auto tile_origin = [&](unsigned v, int &m0_, int &n0_) {
-        const unsigned q = total_tiles >> 3, r = total_tiles & 7, xcd = v & 7;
-        const unsigned logical =
-            (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    const unsigned total_tiles = CHUNK ? p.full_tiles : p.total_tiles;  // tiles the remap covers
+    auto logical_origin = [&](unsigned logical, int &m0_, int &n0_) {
         n0_ = (int)(logical % (unsigned)p.tiles_n) * BN;
         m0_ = (int)(logical / (unsigned)p.tiles_n) * BM;
     };
+    auto tile_origin = [&](unsigned v, int &m0_, int &n0_) {
+        const unsigned q = total_tiles >> 3, r = total_tiles & 7, xcd = v & 7;
+        logical_origin((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3), m0_, n0_);
+    };
     // work item -> tile origin, K range and split index (one item per tile unless K is split)
     auto work_item = [&](unsigned v, int &m0_, int &n0_, int &kb_, int &ke_, int &s_) {
+        if constexpr (CHUNK) {
+            if (v >= p.full_tiles) {  // a piece: one chunk of one tail tile, raw sum to the workspace
+                const unsigned qq = v - p.full_tiles, chunk = qq / p.tail_tiles;
+                logical_origin(p.full_tiles + (qq - chunk * p.tail_tiles), m0_, n0_);
+                kb_ = (int)chunk * p.chunk_L;
+                ke_ = min(kb_ + p.chunk_L, p.nk);
+                s_ = (int)chunk;
+            } else {
+                tile_origin(v, m0_, n0_);
+                kb_ = 0;
+                ke_ = p.nk;
+                s_ = -1;
+            }
+            return;
+        }
         unsigned s = 0;
         if (p.ksplit > 1) {
             s = v / total_tiles;
@@ -378,6 +404,33 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
     const int sw = (li >> 1) & 7;  // swizzle term of this lane's fragment rows
 
     f32x16 acc[MI][NI];
+    // CHUNK: running total of the finished chunks; fold_acc moves the chunk sum into it (the
+    // final call leaves total + last chunk in acc for the epilogue)
+    [[maybe_unused]] f32x16 tot[CHUNK ? MI : 1][CHUNK ? NI : 1];
+    [[maybe_unused]] auto fold_acc = [&](bool have_total) {
+        if constexpr (CHUNK) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float t_ = have_total ? tot[mi][ni][e] + acc[mi][ni][e] : acc[mi][ni][e];
+                        tot[mi][ni][e] = t_;
+                        acc[mi][ni][e] = 0.f;
+                    }
+        }
+    };
+    [[maybe_unused]] auto finish_acc = [&]() {  // acc = total + last chunk
+        if constexpr (CHUNK) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mi][ni][e] = tot[mi][ni][e] + acc[mi][ni][e];
+        }
+    };
 
     // fragment addresses: lane (li, lh) reads chunk 2*ks+lh of its rows: fp32 -> k =
     // 8ks+4lh+{0..3}, bf16 -> k = 16ks+8lh+{0..7} (exactly the operand map of the 32x32x16
@@ -449,7 +502,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
     // squeezed the fragment registers and exposed LDS latency inside the MFMA stream, so
     // large tiles fetch it at the start of the epilogue instead (the accumulators are dead
     // by then).
-    constexpr bool EARLY_RES = PASSES * (int)sizeof(T) <= 16;
+    constexpr bool EARLY_RES = !CHUNK && PASSES * (int)sizeof(T) <= 16;
 
     // residual rows and the channel constants of the CURRENT tile (m0, n0)
     auto prefetch_epilogue = [&]() {
@@ -496,7 +549,16 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
             // loop both loads are unconditional (no phi copies of the staging registers); the
             // last one or two tiles are peeled.
             int kt = kb;
+            [[maybe_unused]] int fold_at = kb + p.chunk_L;  // CHUNK: chunk_L is even
+            [[maybe_unused]] bool folded = false;
             while (kt + 2 < ke) {
+                if constexpr (CHUNK) {
+                    if (kt == fold_at) {  // uniform; only whole tiles get here (a piece is one chunk)
+                        fold_acc(folded);
+                        folded = true;
+                        fold_at += p.chunk_L;
+                    }
+                }
                 load_tile(kt + 1, ra, rb, std::false_type{});
                 compute_tile(Buf0{});
                 store_tile(Buf1{}, ra, rb);
@@ -507,6 +569,12 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
                 __syncthreads();
                 kt += 2;
             }
+            if constexpr (CHUNK) {
+                if (kt == fold_at) {  // the last chunk is the one or two peeled tiles
+                    fold_acc(folded);
+                    folded = true;
+                }
+            }
             if (kt + 1 < ke) {  // two tiles left: kt in buffer 0, kt + 1 still to fetch
                 load_tile(kt + 1, ra, rb, std::false_type{});
                 compute_tile(Buf0{});
@@ -515,6 +583,9 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
                 compute_tile(Buf1{});
             } else {  // one tile left, in buffer 0
                 compute_tile(Buf0{});
+            }
+            if constexpr (CHUNK) {
+                if (folded) finish_acc();  // total + last chunk: the order the pieces are added in
             }
             __syncthreads();
         } else {
@@ -558,7 +629,9 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
     if (vtile == blockIdx.x) stamp(p.stamps, 6);  // ... by every wave
 
     // output of this work item: the tensor itself, or partial-sum slice ks_idx of the workspace
-    void *const out_base = static_cast<char *>(p.out) + (long long)ks_idx * p.split_stride;
+    const bool raw = CHUNK && ks_idx >= 0;  // a piece: plain chunk sum, no epilogue
+    void *const out_base = raw ? static_cast<char *>(p.ws) + (long long)ks_idx * p.ws_stride
+                               : static_cast<char *>(p.out) + (long long)ks_idx * p.split_stride;
     const __amdgpu_buffer_rsrc_t rsrc_o =
         __builtin_amdgcn_make_buffer_rsrc(out_base, 0, p.out_bytes, 0x00020000);
     if (vec) {
@@ -568,9 +641,9 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
         for (int j4 = 0; j4 < EPT / 4; ++j4)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                sc[4 * j4 + j] = has_scale ? __uint_as_float(scv[j4][j]) : 1.f;
+                sc[4 * j4 + j] = (has_scale && !raw) ? __uint_as_float(scv[j4][j]) : 1.f;
                 // -0.0 as the neutral addend keeps a -0.0 convolution result bit-exact
-                sh[4 * j4 + j] = has_shift ? __uint_as_float(shv[j4][j]) : -0.f;
+                sh[4 * j4 + j] = (has_shift && !raw) ? __uint_as_float(shv[j4][j]) : -0.f;
             }
         const bool col_ok = n < p.Cout;
 #pragma unroll
@@ -587,8 +660,8 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
                 float y = fmaf(v[j], sc[j], sh[j]);
-                y = has_res ? y + res[j] : y;
-                v[j] = p.relu ? fmaxf(y, 0.f) : y;
+                y = (has_res && !raw) ? y + res[j] : y;
+                v[j] = (p.relu && !raw) ? fmaxf(y, 0.f) : y;
             }
             const int off = (col_ok && m < p.M) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
             __builtin_amdgcn_raw_buffer_store_b128(OutVec<TO>::pack(v), rsrc_o, off, 0, 0);
@@ -704,7 +777,8 @@ struct FinishParams {
     const float *scale, *shift;
     const void *residual;
     int relu, splits, Cout;
-    uint64_t slice;  // M * Cout
+    uint64_t slice;   // elements to finish (rows * Cout, starting at the pointers given)
+    uint64_t stride;  // elements between consecutive partial slices
 };
 
 template <typename TO>
@@ -714,7 +788,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const FinishParams p
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += gstride) {
         float4 v = *reinterpret_cast<const float4 *>(p.partial + 4 * i);
         for (int s = 1; s < p.splits; ++s) {
-            const float4 x = *reinterpret_cast<const float4 *>(p.partial + (uint64_t)s * p.slice + 4 * i);
+            const float4 x = *reinterpret_cast<const float4 *>(p.partial + (uint64_t)s * p.stride + 4 * i);
             v.x += x.x, v.y += x.y, v.z += x.z, v.w += x.w;
         }
         const int n = (int)((4 * i) % (uint64_t)p.Cout);
@@ -751,13 +825,13 @@ void fast_div(unsigned d, unsigned *mul, unsigned *shr)
 }
 
 // Blocks of one instantiation that fit a CU at once (registers and LDS), asked once.
-template <typename T, typename TO, int BM, int BN, bool DUAL, bool XK>
+template <typename T, typename TO, int BM, int BN, bool DUAL, bool XK, bool CHUNK>
 int resident_blocks_per_cu()
 {
     static int cached = 0;
     if (cached == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_kernel<T, TO, BM, BN, DUAL, XK>, 256,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_kernel<T, TO, BM, BN, DUAL, XK, CHUNK>, 256,
                                                          0) != hipSuccess ||
             nb < 1)
             nb = 1;
@@ -766,15 +840,15 @@ int resident_blocks_per_cu()
     return cached;
 }
 
-template <typename T, typename TO, int BM, int BN, bool DUAL, bool XK>
+template <typename T, typename TO, int BM, int BN, bool DUAL, bool XK, bool CHUNK = false>
 void launch_one(rn_ctx *ctx, GemmParams &p, bool persistent)
 {
     unsigned grid = p.grid_items;
     if (persistent) {
-        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN, DUAL, XK>();
+        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN, DUAL, XK, CHUNK>();
         if (grid > slots) grid = slots;
     }
-    conv_gemm_kernel<T, TO, BM, BN, DUAL, XK><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
+    conv_gemm_kernel<T, TO, BM, BN, DUAL, XK, CHUNK><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
 }
 
 template <typename T, typename TO, bool DUAL = false, bool XK = false>
@@ -788,6 +862,17 @@ void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persist
         launch_one<T, TO, 64, 128, DUAL, XK>(ctx, p, persistent);
     else
         launch_one<T, TO, 64, 64, DUAL, XK>(ctx, p, persistent);
+}
+
+// chunked K sum (fp32 only; the 128x128 tile has no registers to spare for a second accumulator)
+void launch_tiles_chunked(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent)
+{
+    if (BMsel == 128)
+        launch_one<float, float, 128, 64, false, false, true>(ctx, p, persistent);
+    else if (BNsel == 128)
+        launch_one<float, float, 64, 128, false, false, true>(ctx, p, persistent);
+    else
+        launch_one<float, float, 64, 64, false, false, true>(ctx, p, persistent);
 }
 
 // GEMM launch on NHWC data with packed weights.  Caller has checked eligibility.
@@ -890,6 +975,11 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
         }
         persistent = true;
     }
+    // Chunked K sum: a property of the LAYER (element type, kind, K), never of the batch size or
+    // the tile, so that every launch of the layer adds the same products in the same order.
+    const bool chunked = dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32 && !second && !exact &&
+                         p.nk >= 32 && Cout % 4 == 0;
+    if (chunked && BMsel == 128 && BNsel == 128) BNsel = 64;
     const uint64_t tiles_n = rn_ceil_div(Cout, BNsel);
     const uint64_t tiles_m = rn_ceil_div((uint64_t)p.M, BMsel);
     p.tiles_n = (int)tiles_n;
@@ -900,7 +990,11 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     p.kchunk = p.nk;
     p.total_work = p.total_tiles;
     p.split_stride = 0;
-
+    p.chunk_L = p.nk;
+    p.full_tiles = p.total_tiles;
+    p.tail_tiles = 0;
+    p.ws = nullptr;
+    p.ws_stride = 0;
     // Latency mode (rn_ctx_set_split_k): a launch whose tiles cannot fill the chip splits its
     // K loop over several blocks; each writes a raw fp32 partial tile to scratch and a second
     // kernel adds the partials in split order and applies the epilogue.  Deterministic, but
@@ -946,6 +1040,7 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
             f.splits = S;
             f.Cout = (int)Cout;
             f.slice = slice;
+            f.stride = slice;
             const unsigned fgrid = rn_stream_grid(slice / 4, 256);
             if (dt_out == RN_DTYPE_BF16)
                 splitk_finish_kernel<bf16_t><<<fgrid, 256, 0, ctx->stream>>>(f);
@@ -954,6 +1049,46 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
             return rn_after_launch(ctx, what);
         }
     }
+    if (chunked) {
+        // four chunks (the last may be shorter), chunk length even for the two-tile loop trips
+        p.chunk_L = 2 * (int)rn_ceil_div((uint64_t)p.nk, 8);
+        const int S = (int)rn_ceil_div((uint64_t)p.nk, (uint64_t)p.chunk_L);
+        // tail = the tiles past the last full round of the 256 CUs, in whole rows of M tiles;
+        // cutting them into S pieces pays when the pieces need fewer CU rounds than S
+        unsigned tail = (unsigned)(total % 256);
+        tail -= tail % (unsigned)tiles_n;
+        const bool cut = ctx->split_k <= 1 && tail > 0 && total > 256 &&
+                         rn_ceil_div((uint64_t)tail * S, 256) < (uint64_t)S;
+        if (cut) {
+            const uint64_t slice = (uint64_t)p.M * Cout;
+            RN_TRY(rn_scratch(ctx, 4, (uint64_t)S * slice * sizeof(float), &p.ws));
+            p.ws_stride = (long long)(slice * sizeof(float));
+            p.tail_tiles = tail;
+            p.full_tiles = p.total_tiles - tail;
+            p.total_work = p.full_tiles + tail * (unsigned)S;
+        }
+        p.grid_items = p.total_work;
+        launch_tiles_chunked(ctx, p, BMsel, BNsel, persistent);
+        RN_TRY(rn_after_launch(ctx, what));
+        if (cut) {
+            const uint64_t row0 = (uint64_t)(p.full_tiles / (unsigned)tiles_n) * (uint64_t)BMsel;
+            FinishParams f;
+            f.partial = (const float *)p.ws + row0 * Cout;
+            f.out = (float *)out + row0 * Cout;
+            f.scale = p.scale;
+            f.shift = p.shift;
+            f.residual = p.residual ? (const float *)p.residual + row0 * Cout : nullptr;
+            f.relu = p.relu;
+            f.splits = S;
+            f.Cout = (int)Cout;
+            f.slice = ((uint64_t)p.M - row0) * Cout;
+            f.stride = (uint64_t)p.M * Cout;
+            splitk_finish_kernel<float><<<rn_stream_grid(f.slice / 4, 256), 256, 0, ctx->stream>>>(f);
+            return rn_after_launch(ctx, what);
+        }
+        return RN_OK;
+    }
+
     p.grid_items = p.total_tiles;
     if (exact)
         launch_tiles<float, float, false, true>(ctx, p, BMsel, BNsel, persistent);

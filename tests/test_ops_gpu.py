@@ -342,6 +342,32 @@ def test_split_k_latency_mode(case):
     assert np.array_equal(ops.conv2d_nhwc_fused(x, w, s, p, sc, sh, res, True), plain)
 
 
+def test_chunked_k_sum_is_the_same_whole_or_in_pieces():
+    """fp32 layers with K >= 1024 add their products as ((c0 + c1) + c2) + c3 over four K chunks.
+    A launch whose last round would leave most CUs idle cuts its tail tiles into (tile, chunk)
+    pieces and adds them in a second kernel; tiles computed whole fold the chunks in registers.
+    Same bits either way, whatever the batch size or the tile shape."""
+    from resnet_c_amd import _lib as L
+    Cin, Cout, H, W = 1024, 256, 14, 14
+    w = rnd((Cout, Cin, 1, 1), 811)
+    g = np.random.default_rng(812)
+    sc, sh = g.random(Cout, dtype=np.float32) + 0.5, g.standard_normal(Cout, dtype=np.float32)
+    big = rnd((36, Cin, H, W), 813)          # 444 tiles of 64x64: 188 tail tiles are cut
+    got = ops.conv2d_nhwc_fused(big, w, 1, 0, sc, sh, None, True)
+    want = O.relu_(O.conv2d(big[30:], w, 1, 0) * sc[None, :, None, None] + sh[None, :, None, None])
+    assert_close(got[30:], want, Cin + 4)
+    small = ops.conv2d_nhwc_fused(big[34:36], w, 1, 0, sc, sh, None, True)   # 28 tiles, all whole
+    assert np.array_equal(got[34:36], small)
+    assert np.array_equal(got[:2], ops.conv2d_nhwc_fused(big[:2], w, 1, 0, sc, sh, None, True))
+    ctx, lib = R.get_ctx(), L.lib()
+    try:
+        for cand in range(1, lib.rn_conv_tile_candidates() + 1):
+            lib.rn_ctx_set_conv_tile(ctx.handle, cand)
+            assert np.array_equal(ops.conv2d_nhwc_fused(big, w, 1, 0, sc, sh, None, True), got), cand
+    finally:
+        lib.rn_ctx_set_conv_tile(ctx.handle, 0)
+
+
 def test_empty_inputs_are_no_ops():
     """Zero-sized work (B = 0, N = 0, no channels out) returns RN_OK without touching the
     pointers, as a launch with an empty grid would in the reference."""
