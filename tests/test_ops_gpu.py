@@ -368,6 +368,27 @@ def test_chunked_k_sum_is_the_same_whole_or_in_pieces():
         lib.rn_ctx_set_conv_tile(ctx.handle, 0)
 
 
+@pytest.mark.parametrize("case", [(35, 1024, 256, 14, 14, 1, 0),    # ragged last M tile inside the cut tail
+                                  (35, 1024, 264, 14, 14, 1, 0),    # ragged N tile, tail not a whole tile row
+                                  (18, 128, 128, 28, 28, 3, 1)])    # 3x3, K = 1152: 442 tiles, 186 cut
+def test_cut_tails_match_oracle_and_small_batches(case):
+    B, Cin, Cout, H, W, k, p = case
+    seed = 830 + sum(case)
+    x, w = rnd((B, Cin, H, W), seed), rnd((Cout, Cin, k, k), seed + 1)
+    g = np.random.default_rng(seed + 2)
+    sc, sh = g.random(Cout, dtype=np.float32) + 0.5, g.standard_normal(Cout, dtype=np.float32)
+    res = rnd((B, Cout, H, W), seed + 3)
+    got = ops.conv2d_nhwc_fused(x, w, 1, p, sc, sh, res, True)
+    tailrows = slice(B - 2, B)
+    want = O.relu_(O.conv2d(x[tailrows], w, 1, p) * sc[None, :, None, None]
+                   + sh[None, :, None, None] + res[tailrows])
+    assert_close(got[tailrows], want, Cin * k * k + 4)
+    # the last images sit in the cut tail of the big launch and in whole tiles of a small one
+    small = ops.conv2d_nhwc_fused(x[tailrows], w, 1, p, sc, sh, res[tailrows], True)
+    assert np.array_equal(got[tailrows], small)
+    assert np.array_equal(got[:1], ops.conv2d_nhwc_fused(x[:1], w, 1, p, sc, sh, res[:1], True))
+
+
 def test_empty_inputs_are_no_ops():
     """Zero-sized work (B = 0, N = 0, no channels out) returns RN_OK without touching the
     pointers, as a launch with an empty grid would in the reference."""
