@@ -1055,9 +1055,11 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
         const int S = (int)rn_ceil_div((uint64_t)p.nk, (uint64_t)p.chunk_L);
         // tail = the tiles past the last full round of the 256 CUs, in whole rows of M tiles;
         // cutting them into S pieces pays when the pieces need fewer CU rounds than S
-        unsigned tail = (unsigned)(total % 256);
+        // (a launch with at most one round of tiles is all tail: small batches get S times the
+        // blocks, in the same summation order as any other batch size)
+        unsigned tail = total > 256 ? (unsigned)(total % 256) : (unsigned)total;
         tail -= tail % (unsigned)tiles_n;
-        const bool cut = ctx->split_k <= 1 && tail > 0 && total > 256 &&
+        const bool cut = ctx->split_k <= 1 && tail > 0 &&
                          rn_ceil_div((uint64_t)tail * S, 256) < (uint64_t)S;
         if (cut) {
             const uint64_t slice = (uint64_t)p.M * Cout;
