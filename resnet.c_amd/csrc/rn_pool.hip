@@ -34,6 +34,23 @@ __global__ __launch_bounds__(kBlock) void pool_nhwc_vec_kernel(
         const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
         float4 acc = kMax ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        // window inside the image (always so for the global average pool): no bounds tests, so
+        // the loads of a row of taps are independent and issue together; the adds keep the
+        // reference's kh-major order
+        const bool inside = ih0 >= 0 && iw0 >= 0 && ih0 + k <= H && iw0 + k <= W;
+        if (inside && !kMax) {
+            const float4 *row = in4 + ((b * H + ih0) * W + iw0) * C4 + c4;
+            for (int kh = 0; kh < k; ++kh, row += (size_t)W * C4) {
+#pragma unroll 8
+                for (int kw = 0; kw < k; ++kw) {
+                    const float4 v = row[(size_t)kw * C4];
+                    acc.x += v.x;
+                    acc.y += v.y;
+                    acc.z += v.z;
+                    acc.w += v.w;
+                }
+            }
+        } else
         for (int kh = 0; kh < k; ++kh) {
             const int ih = ih0 + kh;
             if (ih < 0 || ih >= H) continue;
