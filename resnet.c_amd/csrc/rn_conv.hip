@@ -1062,10 +1062,16 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
         tail -= tail % (unsigned)tiles_n;
         const bool cut = ctx->split_k <= 1 && tail > 0 &&
                          rn_ceil_div((uint64_t)tail * S, 256) < (uint64_t)S;
+        // the workspace holds only the tail rows [row0, M) of every chunk slice; the kernel
+        // addresses it like the output, through a base moved back by row0 rows
+        uint64_t row0 = 0, tail_elems = 0;
+        void *ws_real = nullptr;
         if (cut) {
-            const uint64_t slice = (uint64_t)p.M * Cout;
-            RN_TRY(rn_scratch(ctx, 4, (uint64_t)S * slice * sizeof(float), &p.ws));
-            p.ws_stride = (long long)(slice * sizeof(float));
+            row0 = (uint64_t)((p.total_tiles - tail) / (unsigned)tiles_n) * (uint64_t)BMsel;
+            tail_elems = ((uint64_t)p.M - row0) * Cout;
+            RN_TRY(rn_scratch(ctx, 4, (uint64_t)S * tail_elems * sizeof(float), &ws_real));
+            p.ws = static_cast<char *>(ws_real) - row0 * Cout * sizeof(float);
+            p.ws_stride = (long long)(tail_elems * sizeof(float));
             p.tail_tiles = tail;
             p.full_tiles = p.total_tiles - tail;
             p.total_work = p.full_tiles + tail * (unsigned)S;
@@ -1074,9 +1080,8 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
         launch_tiles_chunked(ctx, p, BMsel, BNsel, persistent);
         RN_TRY(rn_after_launch(ctx, what));
         if (cut) {
-            const uint64_t row0 = (uint64_t)(p.full_tiles / (unsigned)tiles_n) * (uint64_t)BMsel;
             FinishParams f;
-            f.partial = (const float *)p.ws + row0 * Cout;
+            f.partial = (const float *)ws_real;
             f.out = (float *)out + row0 * Cout;
             f.scale = p.scale;
             f.shift = p.shift;
@@ -1084,8 +1089,8 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
             f.relu = p.relu;
             f.splits = S;
             f.Cout = (int)Cout;
-            f.slice = ((uint64_t)p.M - row0) * Cout;
-            f.stride = (uint64_t)p.M * Cout;
+            f.slice = tail_elems;
+            f.stride = tail_elems;
             splitk_finish_kernel<float><<<rn_stream_grid(f.slice / 4, 256), 256, 0, ctx->stream>>>(f);
             return rn_after_launch(ctx, what);
         }
