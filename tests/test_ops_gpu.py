@@ -388,6 +388,27 @@ def test_cut_tails_match_oracle_and_small_batches(case):
     assert np.array_equal(got[:1], ops.conv2d_nhwc_fused(x[:1], w, 1, p, sc, sh, res[:1], True))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_chunked_layers_random_geometry(seed):
+    """Random batch / image / channel sizes around the point where a launch starts cutting its
+    tail (256-700 tiles): every launch geometry must give the oracle's numbers, and the first
+    and last image must not depend on the others."""
+    g = np.random.default_rng(9000 + seed)
+    k = int(g.choice([1, 3]))
+    Cin = int(g.choice([1024, 1536])) if k == 1 else int(g.choice([128, 160]))   # K >= 1024
+    Cout = int(g.choice([64, 72, 128, 200, 256]))
+    H, W = int(g.integers(5, 15)), int(g.integers(5, 15))
+    tiles_per_image = (H * W / 64.0) * np.ceil(Cout / 64.0)
+    B = int(np.clip(g.integers(256, 700) / tiles_per_image, 2, 64))
+    x, w = rnd((B, Cin, H, W), 9100 + seed), rnd((Cout, Cin, k, k), 9200 + seed)
+    sc, sh = g.random(Cout, dtype=np.float32) + 0.5, g.standard_normal(Cout, dtype=np.float32)
+    got = ops.conv2d_nhwc_fused(x, w, 1, k // 2, sc, sh, None, True)
+    for rows in (slice(0, 1), slice(B - 1, B)):
+        want = O.relu_(O.conv2d(x[rows], w, 1, k // 2) * sc[None, :, None, None] + sh[None, :, None, None])
+        assert_close(got[rows], want, Cin * k * k + 4)
+        assert np.array_equal(got[rows], ops.conv2d_nhwc_fused(x[rows], w, 1, k // 2, sc, sh, None, True))
+
+
 def test_empty_inputs_are_no_ops():
     """Zero-sized work (B = 0, N = 0, no channels out) returns RN_OK without touching the
     pointers, as a launch with an empty grid would in the reference."""
