@@ -316,7 +316,9 @@ RN_API int rn_conv2d_nhwc_pair_forward_dt(rn_ctx *ctx, int dtype, int out_dtype,
  * time; at B=256 the GPU is the bound either way.  Capture runs one eager forward first (arenas
  * and scratch are allocated outside the capture) and bakes in the tile choice of that moment
  * (call rn_model_tune before).  Needs profiling and sync_each_op off (RN_ERR_INVALID otherwise).
- * The buffers must stay valid while the graph lives. */
+ * The buffers must stay valid while the graph lives; while any graph of a context lives, a
+ * call that would have to grow the context's scratch or the model's activation arenas (a
+ * larger batch than any before) returns RN_ERR_INVALID instead of moving them. */
 typedef struct rn_graph rn_graph;
 RN_API int rn_model_capture(rn_model *m, const float *input_nchw, uint64_t B, float *logits,
                             int mode, rn_graph **out);

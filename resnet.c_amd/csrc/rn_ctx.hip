@@ -38,6 +38,10 @@ int rn_scratch(rn_ctx *ctx, int slot, uint64_t bytes, void **ptr)
 {
     if (slot < 0 || slot >= 5) return rn_set_error(ctx, RN_ERR_INVALID, "bad scratch slot");
     if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->graphs_live > 0)
+            return rn_set_error(ctx, RN_ERR_INVALID,
+                                "scratch would have to grow while %d captured graph(s) point into it: "
+                                "destroy them first", ctx->graphs_live);
         // the old block may still be in use by queued kernels
         RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->scratch[slot]) RN_HIP_TRY(ctx, hipFree(ctx->scratch[slot]));
@@ -146,6 +150,9 @@ int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate)
 }
 
 int rn_conv_tile_candidates(void) { return 8; }
+
+// library-internal (rn_model.c is plain C and sees the context only through functions)
+int rn_ctx_graphs_live(const rn_ctx *ctx) { return ctx ? ctx->graphs_live : 0; }
 
 int rn_ctx_set_split_k(rn_ctx *ctx, int max_splits)
 {

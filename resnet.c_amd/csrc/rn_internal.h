@@ -15,6 +15,7 @@ struct rn_ctx {
     int layout;
     int sync_each_op;
     int conv_tile;  // 0 = choose per launch, 1..N = force candidate (tuning)
+    int graphs_live;  // captured forwards that hold pointers into the scratch and the arenas
     int split_k;    // 0 = never split the K loop; n = up to n partial sums per output (latency mode)
     void *debug_stamps;  // diagnostic phase stamps of the contraction kernel, normally null
     // scratch grown on demand (never inside a graph capture; callers that capture

@@ -435,10 +435,14 @@ int rn_model_finalize(rn_model *m)
 #define P_PER_IMG ((uint64_t)56 * 56 * 256) /* == 112*112*64, the stem output */
 #define T_PER_IMG ((uint64_t)56 * 56 * 128) /* layer2.0 conv1 output, the largest mid tensor */
 
+int rn_ctx_graphs_live(const rn_ctx *ctx); /* rn_ctx.hip */
+
 static int ensure_acts(rn_model *m, uint64_t B)
 {
     int st;
     if (B <= m->batch_cap) return RN_OK;
+    if (m->batch_cap > 0 && rn_ctx_graphs_live(m->ctx) > 0)
+        return RN_ERR_INVALID; /* captured graphs point into the arenas: destroy them first */
     free_acts(m);
     {
         const uint64_t es = elem_size(m);

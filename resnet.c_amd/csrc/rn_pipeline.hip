@@ -42,7 +42,10 @@ int rn_graph_destroy(rn_graph *g)
 {
     if (!g) return RN_OK;
     if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
-    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->exec) {
+        (void)hipGraphExecDestroy(g->exec);
+        if (g->ctx) --g->ctx->graphs_live;
+    }
     if (g->graph) (void)hipGraphDestroy(g->graph);
     free(g);
     return RN_OK;
@@ -76,10 +79,16 @@ int rn_model_capture(rn_model *m, const float *input_nchw, uint64_t B, float *lo
         return st != RN_OK ? st : rn_check_hip(ctx, e, "hipStreamEndCapture");
     }
     e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
-    if (e == hipSuccess) e = hipGraphGetNodes(g->graph, nullptr, &g->nodes);
     if (e != hipSuccess) {
+        g->exec = nullptr;
         rn_graph_destroy(g);
         return rn_check_hip(ctx, e, "hipGraphInstantiate");
+    }
+    ++ctx->graphs_live;  // from here on the scratch and the arenas must stay where they are
+    e = hipGraphGetNodes(g->graph, nullptr, &g->nodes);
+    if (e != hipSuccess) {
+        rn_graph_destroy(g);
+        return rn_check_hip(ctx, e, "hipGraphGetNodes");
     }
     *out = g;
     return RN_OK;

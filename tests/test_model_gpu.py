@@ -307,3 +307,26 @@ def test_split_k_model_latency_mode(model50, finch):
     assert np.abs(a - base).max() <= 1e-5 and np.abs(ops_mode - base).max() <= 2e-5
     assert a.argmax(1)[0] == base.argmax(1)[0] == 112
     assert np.array_equal(model50.forward(finch, fused=True), base)
+
+
+def test_live_graph_pins_arenas_and_scratch(state50):
+    """A captured forward holds pointers into the activation arenas and the context scratch: a
+    call that would have to reallocate them (a larger batch) is refused until the graph is gone."""
+    ctx = R.Context(0)
+    m = R.NativeModel("resnet50", state=state50, ctx=ctx)
+    try:
+        x1 = R.weights.generate_input(1, seed=91)
+        x2 = R.weights.generate_input(2, seed=92)
+        want1 = m.forward(x1, fused=True)
+        xd = R.FloatTensor.from_numpy(x1, R.Device.GPU)   # note: allocated through the default ctx
+        out = R.FloatTensor((1, 1000), R.Device.GPU)
+        g = R.Graph(m, xd.data(), 1, out.data(), True)
+        with pytest.raises(R.RnError):
+            m.forward(x2, fused=True)
+        g.launch(); ctx.sync()
+        assert np.array_equal(out.numpy(), want1)
+        g.close()
+        assert m.forward(x2, fused=True).shape == (2, 1000)
+    finally:
+        m.close()
+        ctx.close()
