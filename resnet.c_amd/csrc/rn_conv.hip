@@ -1070,7 +1070,8 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
             row0 = (uint64_t)((p.total_tiles - tail) / (unsigned)tiles_n) * (uint64_t)BMsel;
             tail_elems = ((uint64_t)p.M - row0) * Cout;
             RN_TRY(rn_scratch(ctx, 4, (uint64_t)S * tail_elems * sizeof(float), &ws_real));
-            p.ws = static_cast<char *>(ws_real) - row0 * Cout * sizeof(float);
+            // (integer arithmetic: the moved base lies before the allocation and is never dereferenced)
+            p.ws = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(ws_real) - row0 * Cout * sizeof(float));
             p.ws_stride = (long long)(tail_elems * sizeof(float));
             p.tail_tiles = tail;
             p.full_tiles = p.total_tiles - tail;
