@@ -330,3 +330,34 @@ def test_live_graph_pins_arenas_and_scratch(state50):
     finally:
         m.close()
         ctx.close()
+
+
+def test_two_host_threads_two_contexts(state50):
+    """One context (device, stream, scratch) per host thread, no shared mutable state in the
+    library (SURVEY.md 8(b) threading): two threads run their halves of a batch at the same
+    time and get the bits a single thread gets."""
+    import threading
+    x = R.weights.generate_input(6, seed=123)
+    ref_model = R.NativeModel("resnet50", state=state50)
+    want = ref_model.forward(x, fused=True)
+    ref_model.close()
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            ctx = R.Context(0)
+            m = R.NativeModel("resnet50", state=state50, ctx=ctx)
+            for _ in range(3):
+                results[i] = m.forward(x[3 * i:3 * i + 3], fused=True)
+            m.close()
+            ctx.close()
+        except Exception as e:  # pragma: no cover - surfaced below
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert np.array_equal(np.concatenate(results), want)
