@@ -12,7 +12,12 @@
 //   loadToCpu / loadToCuda / save     same file format         (tensor.cuh:126-163)
 //   view (aliases storage)            same                     (tensor.cuh:165-170)
 //   toDevice / cuda / cpu             rn_memcpy_h2d / d2h      (tensor.cuh:184-209)
-//   gpuAssert: print + abort          rn::check: print + abort (helpers.cuh:13-22)
+//   gpuAssert(code, file, line, abort) same: message on stderr, then abort
+//                                                              (helpers.cuh:13-22)
+//   safeCudaMalloc(size)              rn_malloc, checked; -DDEBUG logs every allocation
+//                                     and the running total    (helpers.cuh:24-35)
+//   <cassert>, <iomanip>, <numeric>   included here as tensor.cuh:4-11 does, so a caller
+//                                     that relied on them (main.cu:171,242) still compiles
 //
 // One process-wide context (device 0 unless rn::set_device() ran first) stands in
 // for CUDA's implicit current device; multi-GPU hosts create one rn_ctx per thread
@@ -20,11 +25,14 @@
 #ifndef RN_TENSOR_HPP
 #define RN_TENSOR_HPP
 
+#include <cassert>
 #include <cstdint>
 #include <cstdlib>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
 #include <memory>
+#include <numeric>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -71,7 +79,30 @@ inline void check(int status, const char *file, int line, bool fatal = true)
 
 }  // namespace rn
 
-#define gpuErrchk(ans) rn::check((ans), __FILE__, __LINE__)
+// gpuErrchk / gpuAssert with the reference's signature (helpers.cuh:8-22); `code` is an
+// rn_hip.h status instead of a cudaError_t
+#define gpuErrchk(ans)                        \
+    {                                         \
+        gpuAssert((ans), __FILE__, __LINE__); \
+    }
+inline void gpuAssert(int code, const char *file, int line, bool abort = true)
+{
+    rn::check(code, file, line, abort);
+}
+
+// checked device allocation on the veneer's context (helpers.cuh:24-35)
+inline void *safeCudaMalloc(uint64_t size)
+{
+    void *dest = nullptr;
+    gpuErrchk(rn_malloc(rn::context(), &dest, size));
+#ifdef DEBUG
+    static uint64_t total = 0;
+    total += size;
+    std::cerr << "GPU allocate ptr: " << dest << ". Size: " << size << " bytes. Total: " << total
+              << " bytes" << std::endl;
+#endif
+    return dest;
+}
 
 enum class Device { CPU, GPU };
 enum class Layout { NCHW = RN_LAYOUT_NCHW, NHWC = RN_LAYOUT_NHWC };
@@ -122,8 +153,7 @@ struct Tensor {
         if (device == Device::CPU) {
             storage_ = std::shared_ptr<T>(static_cast<T *>(std::malloc(size())), std::free);
         } else {
-            void *p = nullptr;
-            gpuErrchk(rn_malloc(rn::context(), &p, size()));
+            void *p = safeCudaMalloc(size());
             storage_ = std::shared_ptr<T>(static_cast<T *>(p),
                                           [](T *q) { rn_free(rn::context(), q); });
         }

@@ -27,6 +27,59 @@ def test_veneer_compiles_with_a_plain_host_compiler(tmp_path):
     assert os.path.exists(_build(tmp_path, "resnet_veneer"))
 
 
+REF_MAIN = "/root/reference/cuda/inference/main.cu"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_MAIN), reason="reference tree only exists in the build container")
+@pytest.mark.parametrize("debug", [False, True])
+def test_reference_caller_compiles_and_links_against_the_veneer(tmp_path, debug):
+    """INTEGRATION.md section 2, literally: the reference's own cuda/inference/main.cu (read where it
+    lies, never copied) compiles with a plain host compiler once its three includes resolve to
+    the veneer -- here through three one-line forwarding headers, which is the include edit of
+    the diff -- and links against librn_hip.so with no extra flags.  -DDEBUG switches on
+    safeCudaMalloc's allocation log (helpers.cuh:28-33)."""
+    for name in ("nn", "ops", "tensor"):
+        (tmp_path / f"{name}.cuh").write_text(f'#include "rn/{name}.hpp"\n')
+    libdir = os.path.dirname(R._lib.LIB_PATH)
+    exe = str(tmp_path / "main_ref")
+    cmd = ["g++", "-x", "c++", "-std=c++20", f"-I{tmp_path}", f"-I{ROOT}/include", REF_MAIN, "-o", exe,
+           f"-L{libdir}", "-lrn_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    if debug:
+        cmd.insert(1, "-DDEBUG")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(exe)
+    # the names the reference's callers use (helpers.cuh:6-35) are all defined by the veneer
+    hdr = open(os.path.join(ROOT, "include", "rn", "tensor.hpp")).read()
+    for name in ("inline void gpuAssert(int code, const char *file, int line, bool abort = true)",
+                 "inline void *safeCudaMalloc(uint64_t size)", "#define gpuErrchk", "#define CEIL",
+                 "#include <cassert>", "#include <iomanip>", "#include <numeric>"):
+        assert name in hdr, name
+
+
+MAIN_REF = os.path.join(ROOT, "oracle", "_ref", "main_ref")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(MAIN_REF),
+                    reason="oracle/_ref/main_ref is built from /root/reference by `make -C oracle` in the build container")
+def test_reference_main_runs_unchanged_on_the_engine(tmp_path, state152, finch, golden_dir):
+    """The reference's own program (cuda/inference/main.cu, compiled by oracle/Makefile against
+    include/rn/*.hpp, not a line changed) run as its author runs it: cwd holds weights_bin/ in
+    the save_weights.py format and test_bins/ILSVRC2012_val_00004749.bin; it builds ResNet-152
+    from the reference-named classes, runs every op through the C-ABI and prints the reference's
+    'max index is N' (main.cu:243-251).  N must be the top-1 of the reference PyTorch module's
+    golden logits on the same generated weights."""
+    os.mkdir(tmp_path / "weights_bin")
+    os.mkdir(tmp_path / "test_bins")
+    R.weights.save_weights_bin(state152, str(tmp_path / "weights_bin"))
+    finch.astype(np.float32).tofile(tmp_path / "test_bins" / "ILSVRC2012_val_00004749.bin")
+    r = subprocess.run([MAIN_REF], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = int(np.load(os.path.join(golden_dir, "resnet152_finch_logits.npy")).argmax(1)[0])
+    assert r.stdout.splitlines()[-1] == f"max index is {want}", r.stdout
+
+
 @pytest.mark.gpu
 def test_veneer_runs_and_matches_oracle(tmp_path):
     from oracle import oracle as O
