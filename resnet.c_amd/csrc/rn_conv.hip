@@ -56,82 +56,13 @@
 // reference's exact summation order ic -> kh -> kw.
 #include <type_traits>
 
-#include "rn_internal.h"
+#include "rn_conv_params.h"
 
 bool rn_conv_is_c4(uint64_t Cin, uint64_t k);
 
+using namespace rn_gemm;
+
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-struct GemmParams {
-    const void *in;
-    const void *w;
-    void *out;
-    const float *scale;
-    const float *shift;
-    const void *residual;  // element type of the output
-    int relu;
-    int H, W, Cs;  // input height, width, elements per input pixel
-    int Ho, Wo, Cout;
-    int KH, KW;  // taps walked by the K loop (small-Cin form: KW = 1)
-    int stride, pad;
-    int cseg;       // 128-byte segments per tap
-    int chunk_dw;   // small-Cin form: pixels per 16-byte chunk (0 otherwise)
-    int c4_chunks;  // small-Cin form: chunks of a segment that carry real taps
-    int M;          // B * Ho * Wo
-    int Ktot;       // packed weight row length in elements
-    int nk;         // K tiles
-    int tiles_n;
-    unsigned total_tiles;  // the grid may be smaller: blocks then walk tiles grid-stride
-    int HoWo;
-    unsigned mul_hw, shr_hw, mul_w, shr_w;  // n / d == umulhi(n, mul) >> shr for n < 2^31
-    unsigned mul_cs, shr_cs, mul_kw, shr_kw;  // K tile -> (tap, segment), tap -> (kh, kw)
-    int in_bytes, w_bytes, out_bytes;
-    // fused pair (DUAL kernels only): K tiles nk1.. come from a second NHWC tensor through a
-    // 1x1 / padding-0 convolution of the same output geometry (the downsample branch)
-    const void *in2;
-    int in2_bytes, H2, W2, Cs2, stride2, nk1;
-    // split K (latency mode): work item v = split * total_tiles + tile; split s sums K tiles
-    // [s*kchunk, min((s+1)*kchunk, nk)) and writes its raw fp32 partial tile to
-    // out + s*split_stride bytes; a second kernel adds the partials in order and finishes
-    int ksplit, kchunk;
-    unsigned total_work;  // total_tiles * ksplit
-    unsigned grid_items;  // host only: blocks of a non-persistent launch
-    long long split_stride;
-    // chunked K sum (CHUNK kernels only): every output of the layer is ((c0 + c1) + c2) + ...
-    // with c_i the sum over K tiles [i*chunk_L, (i+1)*chunk_L).  Tiles below full_tiles fold the
-    // chunks in registers; the last tail_tiles logical tiles are cut into (tile, chunk) pieces
-    // that write their raw chunk sum to ws + chunk*ws_stride (same [M][Cout] addressing as the
-    // output) -- a second kernel adds them in the same order and runs the epilogue.
-    int chunk_L;
-    unsigned full_tiles, tail_tiles;
-    void *ws;
-    long long ws_stride;
-    // exact-K small-Cin form (XK kernels only): K index q = (kh*KW + kw)*Cin + c over a
-    // physically padded image; element q of an A row sits q + (q / kc) * kskip floats after
-    // the row's first element (kc = KW*Cin, kskip = (W - KW)*Cin), zero weight past kreal
-    int kc, kskip, kreal;
-    unsigned mul_kc, shr_kc;
-    // diagnostic only (tools/conv_stamps.py): 16 stamp slots per block, or null
-    unsigned long long *stamps;
-};
-
-typedef __bf16 bf16_t;
-typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
-
-// K tile = one 128-byte row segment: 32 fp32 or 64 bf16 elements; 16-byte chunk = 4 / 8
-template <typename T>
-struct Elem;
-template <>
-struct Elem<float> {
-    static constexpr int CH = 4;
-};
-template <>
-struct Elem<bf16_t> {
-    static constexpr int CH = 8;
-};
 
 constexpr int ROW_FLOATS = 32;  // LDS row = 128 bytes, addressed as 32 dwords
 
@@ -942,6 +873,52 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     p.in_bytes = (int)(B * H * W * (uint64_t)p.Cs * es);
     p.w_bytes = (int)(Cout * (uint64_t)p.Ktot * es);
     p.out_bytes = (int)(B * h_out * w_out * Cout * (uint64_t)(dt_out == RN_DTYPE_BF16 ? 2 : 4));
+
+    // bf16 on 256-wide block tiles (rn_conv_wide.hip): candidates 9.. of the tuner; without a
+    // tuned choice, the K-heavy layers whose tiles fill at least half the chip.  Same k order
+    // per output element as every other candidate, so this too only changes the speed.
+    if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_BF16 && ctx->split_k <= 1) {
+        const int nwide = rn_conv_wide_count();
+        int which = -1;
+        if (ctx->conv_tile > 8 && ctx->conv_tile <= 8 + nwide) {
+            if (rn_conv_wide_eligible(p, ctx->conv_tile - 9)) which = ctx->conv_tile - 9;
+        } else if (ctx->conv_tile == 0 && p.nk >= 8) {
+            static const double eff_wide[4] = {1.00, 0.85, 0.85, 0.60};
+            double best = 1e300;
+            for (int wi = 0; wi < nwide; ++wi) {
+                int bm, bn;
+                rn_conv_wide_tile(wi, &bm, &bn);
+                if (!rn_conv_wide_eligible(p, wi) || (uint64_t)bn > 2 * Cout) continue;
+                const uint64_t tiles = rn_ceil_div((uint64_t)p.M, bm) * rn_ceil_div(Cout, bn);
+                if (tiles < 128) continue;
+                const double cost = (double)rn_ceil_div(tiles, 256) * bm * bn / eff_wide[wi];
+                if (cost < best * 0.999) {
+                    best = cost;
+                    which = wi;
+                }
+            }
+        }
+        if (which >= 0) {
+            int bm, bn;
+            rn_conv_wide_tile(which, &bm, &bn);
+            p.tiles_n = (int)rn_ceil_div(Cout, bn);
+            const uint64_t total = rn_ceil_div((uint64_t)p.M, bm) * (uint64_t)p.tiles_n;
+            RN_REQUIRE(ctx, fits_i32(total), "too many tiles");
+            p.total_tiles = (unsigned)total;
+            p.ksplit = 1;
+            p.kchunk = p.nk;
+            p.total_work = p.total_tiles;
+            p.grid_items = p.total_tiles;
+            p.split_stride = 0;
+            p.chunk_L = p.nk;
+            p.full_tiles = p.total_tiles;
+            p.tail_tiles = 0;
+            p.ws = nullptr;
+            p.ws_stride = 0;
+            rn_conv_wide_launch(ctx, p, which, second != nullptr);
+            return rn_after_launch(ctx, what);
+        }
+    }
 
     // tile choice: the contraction is matrix-core bound, so a launch takes about
     // ceil(tiles / 256 CUs) rounds of one tile's MFMA time; pick the candidate with the

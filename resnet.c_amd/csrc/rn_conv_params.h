@@ -1,0 +1,90 @@
+// Parameters and small types shared by the contraction kernels (rn_conv.hip: the 4-wave
+// kernels for fp32 and bf16; rn_conv_wide.hip: the 8-wave LDS-DMA kernel for bf16).
+#ifndef RN_CONV_PARAMS_H
+#define RN_CONV_PARAMS_H
+
+#include "rn_internal.h"
+
+namespace rn_gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmParams {
+    const void *in;
+    const void *w;
+    void *out;
+    const float *scale;
+    const float *shift;
+    const void *residual;  // element type of the output
+    int relu;
+    int H, W, Cs;  // input height, width, elements per input pixel
+    int Ho, Wo, Cout;
+    int KH, KW;  // taps walked by the K loop (small-Cin form: KW = 1)
+    int stride, pad;
+    int cseg;       // 128-byte segments per tap
+    int chunk_dw;   // small-Cin form: pixels per 16-byte chunk (0 otherwise)
+    int c4_chunks;  // small-Cin form: chunks of a segment that carry real taps
+    int M;          // B * Ho * Wo
+    int Ktot;       // packed weight row length in elements
+    int nk;         // K tiles
+    int tiles_n;
+    unsigned total_tiles;  // the grid may be smaller: blocks then walk tiles grid-stride
+    int HoWo;
+    unsigned mul_hw, shr_hw, mul_w, shr_w;  // n / d == umulhi(n, mul) >> shr for n < 2^31
+    unsigned mul_cs, shr_cs, mul_kw, shr_kw;  // K tile -> (tap, segment), tap -> (kh, kw)
+    int in_bytes, w_bytes, out_bytes;
+    // fused pair (DUAL kernels only): K tiles nk1.. come from a second NHWC tensor through a
+    // 1x1 / padding-0 convolution of the same output geometry (the downsample branch)
+    const void *in2;
+    int in2_bytes, H2, W2, Cs2, stride2, nk1;
+    // split K (latency mode): work item v = split * total_tiles + tile; split s sums K tiles
+    // [s*kchunk, min((s+1)*kchunk, nk)) and writes its raw fp32 partial tile to
+    // out + s*split_stride bytes; a second kernel adds the partials in order and finishes
+    int ksplit, kchunk;
+    unsigned total_work;  // total_tiles * ksplit
+    unsigned grid_items;  // host only: blocks of a non-persistent launch
+    long long split_stride;
+    // chunked K sum (CHUNK kernels only): every output of the layer is ((c0 + c1) + c2) + ...
+    // with c_i the sum over K tiles [i*chunk_L, (i+1)*chunk_L).  Tiles below full_tiles fold the
+    // chunks in registers; the last tail_tiles logical tiles are cut into (tile, chunk) pieces
+    // that write their raw chunk sum to ws + chunk*ws_stride (same [M][Cout] addressing as the
+    // output) -- a second kernel adds them in the same order and runs the epilogue.
+    int chunk_L;
+    unsigned full_tiles, tail_tiles;
+    void *ws;
+    long long ws_stride;
+    // exact-K small-Cin form (XK kernels only): K index q = (kh*KW + kw)*Cin + c over a
+    // physically padded image; element q of an A row sits q + (q / kc) * kskip floats after
+    // the row's first element (kc = KW*Cin, kskip = (W - KW)*Cin), zero weight past kreal
+    int kc, kskip, kreal;
+    unsigned mul_kc, shr_kc;
+    // diagnostic only (tools/conv_stamps.py): 16 stamp slots per block, or null
+    unsigned long long *stamps;
+};
+
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+
+// K tile = one 128-byte row segment: 32 fp32 or 64 bf16 elements; 16-byte chunk = 4 / 8
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr int CH = 4;
+};
+template <>
+struct Elem<bf16_t> {
+    static constexpr int CH = 8;
+};
+
+}  // namespace rn_gemm
+
+// bf16 contraction on 256-wide block tiles (rn_conv_wide.hip).  which: 0 = 256x256, 1 = 256x128,
+// 2 = 128x256, 3 = 256x64.  Caller has checked rn_conv_wide_eligible().
+int rn_conv_wide_count(void);
+bool rn_conv_wide_eligible(const rn_gemm::GemmParams &p, int which);
+void rn_conv_wide_tile(int which, int *bm, int *bn);
+void rn_conv_wide_launch(rn_ctx *ctx, rn_gemm::GemmParams &p, int which, bool dual);
+
+#endif

@@ -1,0 +1,424 @@
+// bf16 contraction on 256-wide block tiles: the K-heavy convolutions of the bf16 network.
+//
+// Same implicit GEMM as conv_gemm_kernel (rn_conv.hip; reference: conv2dForwardKernel,
+// cuda/ops.cu:14-48, on bf16-rounded operands with fp32 sums), same MFMA
+// (v_mfma_f32_32x32x16_bf16), same operand map and the same k order per output element, so
+// every tile candidate of a layer produces the same bits.  What differs is how operands reach
+// the matrix cores.  With 64..128-wide tiles a CU has to pull 64 B/clk of operands through its
+// vector-memory path and push them through ds_write_b128 (79 B/clk) -- the 4-wave kernel stalls
+// there at 600-700 TFLOP/s.  Here:
+//
+//  * block tile 256x256 (also 256x128, 128x256, 256x64): 512 threads = 8 waves, each wave
+//    128x64 (64x64 / 32x64) of 32x32 MFMA tiles; one block per CU, two waves per SIMD.  A
+//    256x256x64 K step is 2048 MFMA cycles per SIMD for 64 KB of operands: 32 B/clk/CU;
+//  * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers,
+//    no ds_write.  One wave instruction moves 8 rows x 128 B; the LDS image is lane-linear, so
+//    the (row>>1)&7 chunk swizzle that makes the ds_read_b128 fragment reads conflict-free is
+//    applied to the per-lane SOURCE offset.  The descriptor's range check writes zeros for a
+//    padded tap or a row past M / Cout, exactly like the register path;
+//  * rings in LDS: three K tiles of A (two in flight while one is multiplied) and two or three
+//    of B; all 160 KB of the CU for the 256x256 tile.  One barrier per K step, with a counted
+//    s_waitcnt vmcnt(N) in front of it: the wave's own pieces of the tile about to be read
+//    have landed, the younger tile stays in flight across the barrier;
+//  * the DMA is issued from inline asm (hipcc would otherwise drain vmcnt(0) in front of every
+//    LDS read); everything else -- fragment reads, MFMAs, the epilogue -- is plain HIP;
+//  * epilogue as in the 4-wave kernel: accumulators -> LDS (fp32, in one or two passes of up to
+//    128 KB) -> row-contiguous 16-byte stores with the channel affine, residual and ReLU.
+//
+// Roofline: MFMA for K >= ~512 and N >= 128 (the 3x3 convolutions, conv1 of layer3/4, the fused
+// conv3 + downsample pairs); short-K layers stay on the 4-wave kernel (rn_model_tune decides).
+#include "rn_conv_params.h"
+
+using namespace rn_gemm;
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int kOob = (int)0x80000000;  // >= num_records of every tensor we accept
+
+// buffer descriptor in four SGPRs for the inline-asm DMA (raw buffer, no swizzle, 32-bit offsets)
+__device__ __forceinline__ i32x4 make_srd(const void *ptr, int bytes)
+{
+    const unsigned long long a = (unsigned long long)ptr;
+    i32x4 r;
+    r[0] = (int)(unsigned)a;
+    r[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+    r[2] = bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+
+// one LDS-DMA wave instruction: lane l fetches 16 bytes at (descriptor base + voff + soff) and
+// the 64 x 16 bytes land at lds_dst + 16*l.  An out-of-range offset lands as zeros.  M0 carries
+// the destination; it is compiler-reserved, so it is saved and restored inside the statement.
+// s_nop 3: the scalar operands may come fresh from a v_readfirstlane (5 wait states to a VMEM
+// read of an SGPR) and M0 needs one before the load.
+__device__ __forceinline__ void dma16(int voff, i32x4 srd, int soff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 3\n\t"
+                 "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(srd), "s"(lds_dst), "s"(soff)
+                 : "memory");
+}
+
+// the wave's DMA pieces of the tile about to be read have landed (N younger ones may stay in
+// flight), its own LDS reads of the previous tile are back, then the block meets
+template <int N>
+__device__ __forceinline__ void wait_and_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ void stamp(unsigned long long *buf, int slot)
+{
+    if (buf && threadIdx.x == 0) buf[(size_t)blockIdx.x * 16 + slot] = wall_clock64();
+}
+
+template <typename TO>
+struct Out;
+template <>
+struct Out<bf16_t> {
+    static constexpr int EPT = 8;
+    static __device__ __forceinline__ void unpack(const i32x4 &r, float (&v)[8])
+    {
+        const bf16x8 x = __builtin_bit_cast(bf16x8, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)x[j];
+    }
+    static __device__ __forceinline__ i32x4 pack(const float (&v)[8])
+    {
+        bf16x8 x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (bf16_t)v[j];  // round to nearest even
+        return __builtin_bit_cast(i32x4, x);
+    }
+};
+
+// BM x BN block tile, WM x WN waves (WM * WN == 8), DUAL as in conv_gemm_kernel
+template <typename TO, int BM, int BN, int WM, int WN, bool DUAL>
+__global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
+{
+    static_assert(WM * WN == 8, "eight waves");
+    constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
+    constexpr int MI = TM / 32, NI = TN / 32;
+    constexpr int PA = BM / 64, PB = BN / 64;  // 1-KiB DMA pieces per wave and K tile
+    static_assert(PA >= 1 && PB >= 1 && MI >= 1 && NI >= 1, "tile too small for eight waves");
+    constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128;  // bytes of one K tile of A / of B
+    constexpr int SA = 3;
+    constexpr int SB = 3 * (A_SLOT + B_SLOT) <= 160 * 1024 ? 3 : 2;
+    constexpr int LDS_BYTES = SA * A_SLOT + SB * B_SLOT;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    // epilogue staging: the fp32 tile in one pass, or its two halves of BM/2 rows
+    constexpr int CPASS = BM * BN * 4 <= LDS_BYTES ? 1 : 2;
+    constexpr int EROWS = BM / CPASS;
+    static_assert(EROWS * BN * 4 <= LDS_BYTES && EROWS % TM == 0, "epilogue staging");
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+    stamp(p.stamps, 0);
+    // XCD-aware tile order, as conv_gemm_kernel: each XCD walks a contiguous range of tiles with
+    // the N tiles of one M panel adjacent
+    int m0, n0;
+    {
+        const unsigned total = p.total_tiles, v = blockIdx.x;
+        const unsigned q = total >> 3, r = total & 7, xcd = v & 7;
+        const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        n0 = (int)(logical % (unsigned)p.tiles_n) * BN;
+        m0 = (int)(logical / (unsigned)p.tiles_n) * BM;
+    }
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const i32x4 srd_a = make_srd(p.in, p.in_bytes);
+    const i32x4 srd_b = make_srd(p.w, p.w_bytes);
+    const i32x4 srd_a2 = make_srd(DUAL ? p.in2 : p.in, DUAL ? p.in2_bytes : 0);
+    const unsigned lds_base = (unsigned)(uintptr_t)((lds_void *)lds);
+
+    // DMA geometry: piece q = 8*j + wave of an operand tile covers tile rows 8q .. 8q+7; lane l
+    // fills (row 8q + l/8, physical chunk l%8) and therefore fetches logical chunk
+    // (l%8) ^ ((row>>1)&7).  Per piece and lane: byte offset of tap (0,0) of the row, and which
+    // taps are inside the image (bit kh of the low half, bit kw of the high half).
+    const int prow = lane >> 3, pc = lane & 7;
+    int a_off[PA], a_mask[PA], a_cur[PA], b_off[PB];
+    int a_off2[DUAL ? PA : 1];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) {
+        const int r = 8 * (8 * j + wave) + prow;
+        const int chunk = (pc ^ ((r >> 1) & 7)) * 16;
+        const int m = m0 + r;
+        if (m < p.M) {
+            const int b = p.HoWo == 1 ? m : (int)(__umulhi((unsigned)m, p.mul_hw) >> p.shr_hw);
+            const int rem = m - b * p.HoWo;
+            const int oh = p.Wo == 1 ? rem : (int)(__umulhi((unsigned)rem, p.mul_w) >> p.shr_w);
+            const int ow = rem - oh * p.Wo;
+            const int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+            a_off[j] = ((b * p.H + ih0) * p.W + iw0) * p.Cs * 2 + chunk;
+            const int rlo = max(0, -ih0), rhi = min(p.KH, p.H - ih0);
+            const int clo = max(0, -iw0), chi = min(p.KW, p.W - iw0);
+            const int rm = rhi > rlo ? ((1 << rhi) - 1) & ~((1 << rlo) - 1) : 0;
+            const int cm = chi > clo ? ((1 << chi) - 1) & ~((1 << clo) - 1) : 0;
+            a_mask[j] = rm | (cm << 16);
+            if constexpr (DUAL)
+                a_off2[j] = ((b * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.Cs2 * 2 + chunk;
+        } else {
+            a_off[j] = 0;
+            a_mask[j] = 0;
+            if constexpr (DUAL) a_off2[j] = kOob;
+        }
+        a_cur[j] = kOob;
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int r = 8 * (8 * j + wave) + prow;
+        const int n = n0 + r;
+        b_off[j] = n < p.Cout ? n * p.Ktot * 2 + (pc ^ ((r >> 1) & 7)) * 16 : kOob;
+    }
+
+    // K tile kt of A into ring slot `slot`.  The K position (tap, 128-byte segment) is scalar
+    // arithmetic; the per-row offsets change only when the tap does, the segments of one tap go
+    // through the scalar offset.  Tiles are issued in increasing kt from 0, so a tap's first
+    // segment always passes here before its others.
+    auto issue_a = [&](int kt, int slot) {
+        const unsigned s_kt = (unsigned)__builtin_amdgcn_readfirstlane(kt);
+        int s_cs;
+        i32x4 srd = srd_a;
+        if (DUAL && s_kt >= (unsigned)p.nk1) {
+            s_cs = (int)s_kt - p.nk1;
+            srd = srd_a2;
+            if (s_cs == 0) {
+#pragma unroll
+                for (int j = 0; j < PA; ++j) a_cur[j] = a_off2[DUAL ? j : 0];
+            }
+        } else {
+            const unsigned tap = p.cseg == 1 ? s_kt : (__umulhi(s_kt, p.mul_cs) >> p.shr_cs);
+            s_cs = (int)(s_kt - tap * (unsigned)p.cseg);
+            if (s_cs == 0) {
+                const unsigned ukh = p.KW == 1 ? tap : (__umulhi(tap, p.mul_kw) >> p.shr_kw);
+                const int s_kh = (int)ukh, s_kw = (int)(tap - ukh * (unsigned)p.KW);
+                const int toff = (s_kh * p.W + s_kw) * p.Cs * 2;
+#pragma unroll
+                for (int j = 0; j < PA; ++j) {
+                    const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
+                    a_cur[j] = ok ? a_off[j] + toff : kOob;
+                }
+            }
+        }
+        const int seg = s_cs * 128;
+        const unsigned dst = lds_base + (unsigned)(slot * A_SLOT + wave * 1024);
+#pragma unroll
+        for (int j = 0; j < PA; ++j) dma16(a_cur[j], srd, seg, dst + (unsigned)(j * 8192));
+    };
+    auto issue_b = [&](int kt, int slot) {
+        const int soff = __builtin_amdgcn_readfirstlane(kt) * 128;
+        const unsigned dst = lds_base + (unsigned)(SA * A_SLOT + slot * B_SLOT + wave * 1024);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) dma16(b_off[j], srd_b, soff, dst + (unsigned)(j * 8192));
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.f;
+
+    // fragment reads: lane (li, lh) reads chunk 2*ks+lh of its rows -> k = 16ks + 8lh + {0..7},
+    // the operand map of the 32x32x16 MFMA; (row>>1)&7 of rows base+32i+li is that of li
+    const int sw = (li >> 1) & 7;
+    int frag_co[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) frag_co[ks] = ((2 * ks + lh) ^ sw) * 16;
+    const int a_thr = (wm * TM + li) * 128, b_thr = SA * A_SLOT + (wn * TN + li) * 128;
+    // fragment reads and MFMAs of one K tile; hipcc's own interleave of the two (measured: an
+    // explicit one-step-ahead fragment prefetch was 8-15 % slower)
+    auto compute = [&](int sa, int sb) {
+        const char *const abase = lds + a_thr + sa * A_SLOT;
+        const char *const bbase = lds + b_thr + sb * B_SLOT;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            i32x4 a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                a[mi] = *reinterpret_cast<const i32x4 *>(abase + frag_co[ks] + mi * 4096);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                b[ni] = *reinterpret_cast<const i32x4 *>(bbase + frag_co[ks] + ni * 4096);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni],
+                        0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- K loop ----------------------------------------------------------------------------
+    // issue order is what the counted waits rely on:
+    //   SB == 3:  prologue A0 B0 A1 B1; step t issues A(t+2) B(t+2);  wait leaves A(t+1) B(t+1)
+    //   SB == 2:  prologue A0 B0 A1;    step t issues B(t+1) A(t+2);  wait leaves A(t+1)
+    const int nk = p.nk;
+    issue_a(0, 0);
+    issue_b(0, 0);
+    if (nk > 1) {
+        issue_a(1, 1);
+        if constexpr (SB == 3) issue_b(1, 1);
+    }
+    int sa = 0, sb = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk)
+            wait_and_barrier<SB == 3 ? PA + PB : PA>();
+        else
+            wait_and_barrier<0>();
+        if (kt == 0) stamp(p.stamps, 1);
+        // every wave is past its reads of tile kt-1: its slots take the tiles after next
+        if constexpr (SB == 3) {
+            if (kt + 2 < nk) {
+                const int s2 = sa == 0 ? 2 : sa - 1;
+                issue_a(kt + 2, s2);
+                issue_b(kt + 2, sb == 0 ? 2 : sb - 1);
+            }
+        } else {
+            if (kt + 1 < nk) issue_b(kt + 1, sb ^ 1);
+            if (kt + 2 < nk) issue_a(kt + 2, sa == 0 ? 2 : sa - 1);
+        }
+        compute(sa, sb);
+        sa = sa == SA - 1 ? 0 : sa + 1;
+        sb = sb == SB - 1 ? 0 : sb + 1;
+    }
+    wait_and_barrier<0>();  // every wave is done with the rings: they become the C staging area
+    stamp(p.stamps, 2);
+
+    // ---- epilogue ----------------------------------------------------------------------------
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); one
+    // ds_write_b32 per register puts 32 consecutive columns of two rows, conflict-free.  Then
+    // 16 bytes of one output row per thread and step: channel affine, residual, ReLU, store.
+    constexpr int EPT = Out<TO>::EPT;
+    constexpr int CV = BN / EPT, RPP = 512 / CV, STEPS = EROWS / RPP;
+    static_assert(STEPS >= 1 && EROWS % RPP == 0, "epilogue geometry");
+    const int cv = t % CV, rr = t / CV;
+    const int n = n0 + cv * EPT;
+    const bool col_ok = n < p.Cout;  // Cout % 8 == 0 (eligibility): then n + 8 <= Cout
+    const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
+    const bool has_res = p.residual != nullptr;
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
+        has_res ? const_cast<void *>(p.residual) : p.out, 0, has_res ? p.out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(
+        has_scale ? (void *)const_cast<float *>(p.scale) : p.out, 0, has_scale ? p.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_sh = __builtin_amdgcn_make_buffer_rsrc(
+        has_shift ? (void *)const_cast<float *>(p.shift) : p.out, 0, has_shift ? p.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    float sc[EPT], sh[EPT];
+#pragma unroll
+    for (int j4 = 0; j4 < EPT / 4; ++j4) {
+        const i32x4 s4 = __builtin_bit_cast(
+            i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_sc, col_ok ? (n + 4 * j4) * 4 : kOob, 0, 0));
+        const i32x4 h4 = __builtin_bit_cast(
+            i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_sh, col_ok ? (n + 4 * j4) * 4 : kOob, 0, 0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[4 * j4 + j] = has_scale ? __int_as_float(s4[j]) : 1.f;
+            sh[4 * j4 + j] = has_shift ? __int_as_float(h4[j]) : -0.f;  // -0.0 keeps a -0.0 sum
+        }
+    }
+    float *const Cs = reinterpret_cast<float *>(lds);  // [EROWS][BN] fp32
+#pragma unroll
+    for (int pass = 0; pass < CPASS; ++pass) {
+        const int row0 = pass * EROWS;  // first tile row of this pass
+        i32x4 resv[STEPS];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int m = m0 + row0 + rr + s * RPP;
+            const int off = (col_ok && m < p.M) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
+            resv[s] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, off, 0, 0));
+        }
+        if (wm * TM >= row0 && wm * TM < row0 + EROWS) {  // wave-uniform
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    float *dst = Cs + (wm * TM - row0 + mi * 32 + 4 * lh) * BN + wn * TN + ni * 32 + li;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[mi][ni][e];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int row = rr + s * RPP;
+            const int m = m0 + row0 + row;
+            float v[EPT], res[EPT];
+            Out<TO>::unpack(resv[s], res);
+#pragma unroll
+            for (int j4 = 0; j4 < EPT / 4; ++j4) {
+                const float4 x = *reinterpret_cast<const float4 *>(Cs + row * BN + cv * EPT + 4 * j4);
+                v[4 * j4] = x.x, v[4 * j4 + 1] = x.y, v[4 * j4 + 2] = x.z, v[4 * j4 + 3] = x.w;
+            }
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                float y = fmaf(v[j], sc[j], sh[j]);
+                y = has_res ? y + res[j] : y;
+                v[j] = p.relu ? fmaxf(y, 0.f) : y;
+            }
+            const int off = (col_ok && m < p.M) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Out<TO>::pack(v)), rsrc_o, off, 0, 0);
+        }
+        if (pass + 1 < CPASS) __syncthreads();
+    }
+    stamp(p.stamps, 3);
+}
+
+struct WideTile {
+    int bm, bn;
+};
+constexpr WideTile kTiles[] = {{256, 256}, {256, 128}, {128, 256}, {256, 64}};
+constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
+
+template <int BM, int BN, int WM, int WN>
+void launch(rn_ctx *ctx, const GemmParams &p, bool dual)
+{
+    if (dual)
+        conv_wide_kernel<bf16_t, BM, BN, WM, WN, true><<<dim3(p.total_tiles), dim3(512), 0, ctx->stream>>>(p);
+    else
+        conv_wide_kernel<bf16_t, BM, BN, WM, WN, false><<<dim3(p.total_tiles), dim3(512), 0, ctx->stream>>>(p);
+}
+
+}  // namespace
+
+int rn_conv_wide_count(void) { return kNumTiles; }
+
+void rn_conv_wide_tile(int which, int *bm, int *bn)
+{
+    *bm = kTiles[which].bm;
+    *bn = kTiles[which].bn;
+}
+
+// bf16 in and out, whole 128-byte channel segments (not the small-Cin stem forms), 16-byte
+// output rows, K unsplit; the caller has filled the shape fields of p
+bool rn_conv_wide_eligible(const GemmParams &p, int which)
+{
+    if (which < 0 || which >= kNumTiles) return false;
+    return p.chunk_dw == 0 && p.kreal == 0 && p.Cout % 8 == 0 && p.nk >= 1;
+}
+
+void rn_conv_wide_launch(rn_ctx *ctx, GemmParams &p, int which, bool dual)
+{
+    switch (which) {
+    case 0: launch<256, 256, 2, 4>(ctx, p, dual); break;
+    case 1: launch<256, 128, 4, 2>(ctx, p, dual); break;
+    case 2: launch<128, 256, 2, 4>(ctx, p, dual); break;
+    default: launch<256, 64, 8, 1>(ctx, p, dual); break;
+    }
+}

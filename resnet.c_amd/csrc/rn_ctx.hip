@@ -5,7 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "rn_internal.h"
+#include "rn_conv_params.h"
 
 int rn_set_error(rn_ctx *ctx, int status, const char *fmt, ...)
 {
@@ -149,7 +149,7 @@ int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate)
     return RN_OK;
 }
 
-int rn_conv_tile_candidates(void) { return 8; }
+int rn_conv_tile_candidates(void) { return 8 + rn_conv_wide_count(); }
 
 // library-internal (rn_model.c is plain C and sees the context only through functions)
 int rn_ctx_graphs_live(const rn_ctx *ctx) { return ctx ? ctx->graphs_live : 0; }

@@ -43,6 +43,65 @@ def test_bf16_conv_matches_oracle_on_rounded_operands(case):
     assert np.array_equal(got16, ops.bf16_round(got32))  # bf16 output = RNE of the fp32 result
 
 
+WIDE_CASES = [(3, 64, 64, 20, 20, 3, 1, 1),      # 1200 rows: ragged last M tile, padded taps
+              (2, 128, 256, 17, 15, 3, 2, 1),    # stride 2, odd image, two channel segments per tap
+              (5, 256, 96, 9, 9, 1, 1, 0),       # N tile wider than Cout
+              (2, 512, 520, 8, 8, 1, 2, 0),      # ragged N tile, strided 1x1
+              (1, 64, 64, 6, 6, 3, 1, 1)]        # one K tile per tap, a single ragged tile
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_bf16_every_tile_candidate_matches_oracle_and_each_other(case):
+    """Candidates 1-8 are the 4-wave kernel's tiles, 9.. the 8-wave LDS-DMA kernel's 256-wide
+    tiles (rn_conv_wide.hip): each against the oracle on bf16-rounded operands (padded taps,
+    rows past M and channels past Cout must come out of the DMA as zeros), and all with the
+    same bits -- the k order per output element does not depend on the tile."""
+    from resnet_c_amd import _lib as L
+    B, Cin, Cout, H, W, k, s, p = case
+    x, w = rnd((B, Cin, H, W), 107 + sum(case)), rnd((Cout, Cin, k, k), 108 + sum(case)) / np.sqrt(Cin * k * k)
+    g = np.random.default_rng(109 + sum(case))
+    scale, shift = g.random(Cout, dtype=np.float32) + 0.5, g.standard_normal(Cout, dtype=np.float32)
+    ho, wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = rnd((B, Cout, ho, wo), 110 + sum(case))
+    y = O.conv2d(ops.bf16_round(x), ops.bf16_round(w), s, p)
+    want = np.maximum(y * scale[None, :, None, None] + shift[None, :, None, None] + ops.bf16_round(res), 0)
+    ctx, lib = R.get_ctx(), L.lib()
+    base = ops.conv2d_nhwc_bf16(x, w, s, p, scale, shift, res, True)
+    assert np.abs(base - want).max() <= 2 ** -8 * np.abs(want).max() + 1e-5
+    plain = ops.conv2d_nhwc_bf16(x, w, s, p)
+    try:
+        for cand in range(1, lib.rn_conv_tile_candidates() + 1):
+            lib.rn_ctx_set_conv_tile(ctx.handle, cand)
+            assert np.array_equal(ops.conv2d_nhwc_bf16(x, w, s, p, scale, shift, res, True), base), cand
+            assert np.array_equal(ops.conv2d_nhwc_bf16(x, w, s, p), plain), cand
+    finally:
+        lib.rn_ctx_set_conv_tile(ctx.handle, 0)
+
+
+def test_bf16_conv_pair_every_tile_candidate():
+    from resnet_c_amd import _lib as L
+    B, Cin, Cout, H, W, Cin2, s2 = 3, 128, 256, 10, 10, 64, 2
+    t, w = rnd((B, Cin, H, W), 171), rnd((Cout, Cin, 1, 1), 172)
+    x2, w2 = rnd((B, Cin2, 19, 19), 173), rnd((Cout, Cin2, 1, 1), 174)
+    g = np.random.default_rng(175)
+    sc1, sc2 = g.random(Cout, dtype=np.float32) + 0.5, g.random(Cout, dtype=np.float32) + 0.5
+    shift = g.standard_normal(Cout, dtype=np.float32)
+    ctx, lib = R.get_ctx(), L.lib()
+    base = ops.conv2d_nhwc_pair(t, w, x2, w2, 1, 0, s2, sc1, sc2, shift, None, True, bf16=True)
+    tb, xb = ops.bf16_round(t), ops.bf16_round(x2)
+    w1b = ops.bf16_round(w * sc1[:, None, None, None])
+    w2b = ops.bf16_round(w2 * sc2[:, None, None, None])
+    want = O.relu_(O.conv2d(tb, w1b, 1, 0) + O.conv2d(xb, w2b, s2, 0) + shift[None, :, None, None])
+    np.testing.assert_allclose(base, ops.bf16_round(want), rtol=2 ** -7, atol=2e-2)
+    try:
+        for cand in range(1, lib.rn_conv_tile_candidates() + 1):
+            lib.rn_ctx_set_conv_tile(ctx.handle, cand)
+            got = ops.conv2d_nhwc_pair(t, w, x2, w2, 1, 0, s2, sc1, sc2, shift, None, True, bf16=True)
+            assert np.array_equal(got, base), cand
+    finally:
+        lib.rn_ctx_set_conv_tile(ctx.handle, 0)
+
+
 def test_bf16_fused_epilogue():
     B, Cin, Cout, H, W = 2, 64, 128, 9, 9
     x, w = rnd((B, Cin, H, W), 1), rnd((Cout, Cin, 3, 3), 2) / 24
