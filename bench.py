@@ -129,21 +129,23 @@ def cpu_baseline(arch: str, state, seconds_budget: float = 15.0):
 
 
 def pmc_traffic(args):
-    """HBM bytes per launch of the contraction kernel from the committed rocprofv3 --pmc passes
-    (profiles/round*/final_hbm_traffic_pmc.json, made by tools/pmc_traffic.py); counters cannot
-    be read from inside this process, so other configurations report null."""
-    if not (args.arch == "resnet50" and args.batch == 256 and args.dtype == "f32"
-            and args.mode == "fused"):
-        return None
+    """(HBM bytes per launch of the contraction kernels, file they come from).  Hardware counters
+    cannot be read from inside this process: the figure is the one of the committed rocprofv3
+    --pmc passes of this same command (profiles/round*/final_hbm_traffic_pmc*.json, made by
+    tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950),
+    NOT a measurement of this run; configurations without such a file report null."""
+    if not (args.arch == "resnet50" and args.batch == 256 and args.mode == "fused"):
+        return None, None
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "final_hbm_traffic_pmc.json")))
+    name = "final_hbm_traffic_pmc.json" if args.dtype == "f32" else f"final_hbm_traffic_pmc_{args.dtype}.json"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", name)))
     if not files:
-        return None
+        return None, None
     try:
-        return round(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+        return round(json.load(open(files[-1]))["traffic_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
 
 
 def summarize_profile(recs, n_forwards: int):
@@ -225,6 +227,20 @@ def main():
     R.set_device(device_index)
     ctx = R.get_ctx()
 
+    # who takes part: the launcher's world size as torch.distributed sees it, and every rank's device
+    me = {"rank": rank, "local_rank": local_rank, "device_index": device_index,
+          "device": torch.cuda.get_device_name(device_index), "pid": os.getpid()}
+    ranks = [me]
+    dist_world, dist_backend = 1, None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist_world, dist_backend = dist.get_world_size(), dist.get_backend()
+        ranks = [None] * dist_world
+        dist.all_gather_object(ranks, me)
+    print(f"bench: rank {rank}/{dist_world} ({dist_backend or 'single process'}) on cuda:{device_index} "
+          f"{me['device']}", file=sys.stderr, flush=True)
+
     B = args.batch
     state = R.weights.generate_state(args.arch, seed=0)
     model = R.NativeModel(args.arch, state=state, ctx=ctx, dtype=args.dtype)
@@ -263,9 +279,12 @@ def main():
     # per-kernel durations: HIP events on the library's stream around every op
     model.set_profiling(True)
     recs = []
+    lib = R._lib.lib()
+    launches0 = lib.rn_ctx_launch_count(ctx.handle)
     for _ in range(args.profile_forwards):
         model.forward_ptr(x_dev.data(), B, logits.data(), fused)
         recs += model.profile()
+    kernel_launches = (lib.rn_ctx_launch_count(ctx.handle) - launches0) // max(1, args.profile_forwards)
     model.set_profiling(False)
     fam = summarize_profile(recs, max(1, args.profile_forwards))
 
@@ -277,7 +296,11 @@ def main():
     g_flops = sum(fam[k]["flops"] for k in gemm_names)
     g_ms = sum(fam[k]["ms"] for k in gemm_names)
     g_bytes = sum(fam[k]["bytes"] for k in gemm_names)
-    g_launch = sum(fam[k]["launches"] for k in gemm_names)
+    g_ops = sum(fam[k]["launches"] for k in gemm_names)
+    # kernel launches of the contraction family: one per op record plus the launches that add the
+    # K-chunk pieces of cut tail tiles (their time is inside the op's event bracket)
+    other_ops = sum(f["launches"] for k, f in fam.items() if k not in gemm_names)
+    g_launch = int(kernel_launches) - other_ops
     achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
     hbm = {}
     for k, f in fam.items():
@@ -288,6 +311,12 @@ def main():
                   "GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     prec = "fp32" if args.dtype == "f32" else "bf16"
+    g_gbps = g_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
+    # what binds the contraction family as a whole: the larger of its two roofline fractions
+    # (fp32: the matrix pipe; bf16 storage: 16x the matrix rate on half the bytes -> HBM)
+    frac_mfma, frac_hbm = achieved / peak, g_gbps / PEAK_HBM_GBS
+    bound = "mfma" if frac_mfma >= frac_hbm else "hbm"
+    traffic, traffic_source = pmc_traffic(args)
     result = {
         "metric": "images/sec ResNet-50 224x224 fp32 batch=256"
                   if args.arch == "resnet50" and B == 256 and args.dtype == "f32"
@@ -311,14 +340,22 @@ def main():
                    "global_batch": world * B, "batch_per_gpu": B,
                    "mode": "fused conv+bn+relu(+add) epilogues" if fused else "one kernel per reference op",
                    "parallelism": f"batch split over {world} GPU(s), weights replicated, no collective"},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": pmc_traffic(args),
-                     "kernel": "conv_gemm_kernel (implicit-GEMM conv2d + fc on " +
+        "roofline": {"bound": bound,
+                     "achieved": round(achieved, 2) if bound == "mfma" else round(g_gbps, 1),
+                     "peak": peak if bound == "mfma" else PEAK_HBM_GBS,
+                     "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                     "frac": round(max(frac_mfma, frac_hbm), 4),
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": "conv_gemm_kernel" + (" / conv_wide_kernel" if args.dtype == "bf16" else "") +
+                               " (implicit-GEMM conv2d + fc on " +
                                ("v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else "v_mfma_f32_32x32x16_bf16)"),
-                     "hbm_GBps": round(g_bytes / (g_ms * 1e-3) / 1e9, 1) if g_ms > 0 else 0.0,
-                     "launches_per_forward": g_launch,
-                     "flops_per_forward": g_flops, "ms_per_forward": round(g_ms, 4)},
+                     "mfma_TFLOPs": round(achieved, 2), "mfma_frac": round(frac_mfma, 4),
+                     "hbm_GBps": round(g_gbps, 1), "hbm_frac": round(frac_hbm, 4),
+                     "ops_per_forward": g_ops, "launches_per_forward": g_launch,
+                     "avg_launch_us": round(g_ms * 1e3 / max(g_launch, 1), 2),
+                     "flops_per_forward": g_flops, "bytes_per_forward": g_bytes,
+                     "ms_per_forward": round(g_ms, 4)},
+        "world": {"size": dist_world, "backend": dist_backend, "ranks": ranks},
         "whole_step_mfma_frac": round(value / world * GFLOP_PER_IMAGE[args.arch] / 1e3 / peak, 4),
         "hbm_kernels": hbm,
     }

@@ -63,6 +63,7 @@ inline rn_ctx *context()
             std::abort();
         }
         rn_ctx_set_sync_each_op(c, 1);  // the reference synchronises after every op
+        rn_ctx_set_weight_cache(c, 1);  // layers own their weights (nn.cuh:13): pack each once
         return c;
     }();
     return ctx;

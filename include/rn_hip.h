@@ -41,7 +41,9 @@
  * conv, pool and linear must not alias.
  *
  * Threading: one context per host thread; a context = (device, stream,
- * scratch).  No global mutable state.
+ * scratch).  No global mutable state.  A host thread may own contexts on
+ * several devices: every entry point makes its context's device the calling
+ * thread's current HIP device before it touches the device.
  */
 #ifndef RN_HIP_H
 #define RN_HIP_H
@@ -92,6 +94,16 @@ RN_API int rn_ctx_get_layout(const rn_ctx *ctx);
 RN_API int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on);
 /* Tile shape of the contraction kernel: 0 = chosen per launch (default), 1..N = force
  * candidate i (all candidates give bit-identical results; used by rn_model_tune). */
+/* rn_conv2d_forward (the reference's OIHW / NCHW signature) re-packs the weight into the
+ * engine's K-major panel on every call.  With the cache on, the panel is packed once per
+ * (weight buffer, shape) and reused; entries die when the buffer is rn_free'd or written by
+ * rn_memcpy_h2d / rn_memcpy_d2d / rn_memset.  A caller that turns it on promises not to change
+ * a weight buffer by any other means (the reference's layers own their weights and never
+ * do: nn.cuh:13,47-48,104).  Off by default; the C++ veneer turns it on. */
+RN_API int rn_ctx_set_weight_cache(rn_ctx *ctx, int on);
+/* kernel launches issued through this context so far (a contraction whose tail tiles are cut
+ * into K chunks is two launches: the pieces and the kernel that adds them) */
+RN_API uint64_t rn_ctx_launch_count(const rn_ctx *ctx);
 RN_API int rn_conv_tile_candidates(void);
 RN_API int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate);
 /* Latency mode: max_splits > 1 lets a contraction whose output tiles cannot fill the chip
@@ -197,7 +209,9 @@ RN_API int rn_conv2d_nhwc_forward(rn_ctx *ctx, const float *inp, float *out,
 /* ---- element-type tagged engine entry points (bf16 storage, fp32 accumulate) ---------
  * The fp32 functions above are the dtype == RN_DTYPE_F32 case of these.  bf16 tensors
  * are NHWC only, 16-byte aligned, convolution in_channels a multiple of 64 (or the
- * small-Cin stem form reading an image that carries its own zero border).           */
+ * small-Cin stem form, in_channels <= 4 and kernel_size <= 8, reading a 4-channel image that
+ * carries its own zero border: padding = 0, even stride and width; its K tile is 8 pixels of
+ * each of two consecutive image rows, so the 7x7 stem is 4 K tiles).                 */
 RN_API uint64_t rn_conv2d_packed_weight_numel_dt(int dtype, uint64_t in_channels,
                                                  uint64_t out_channels, uint64_t kernel_size);
 /* fp32 OIHW weights (the weights_bin order) -> K-major panel of `dtype` */
@@ -345,6 +359,29 @@ RN_API int rn_pipeline_submit(rn_pipeline *p, const float *host_input_nchw);
 /* host_logits: B*1000 floats.  RN_ERR_INVALID when nothing is in flight. */
 RN_API int rn_pipeline_collect(rn_pipeline *p, float *host_logits);
 RN_API uint64_t rn_pipeline_in_flight(const rn_pipeline *p);
+
+/* ---- one batch over several devices of a node ---------------------------------------
+ * The multi-device form of the reference's main() (main.cu:228-254).  The forward has no
+ * cross-image reduction, so the batch shards contiguously (shard g of G owns images
+ * [lo, hi) of rn_shard_bounds), weights are replicated, no data moves between devices and the
+ * logits are concatenated on the host.  One host thread + one context + one model per listed
+ * device, created and driven by the group; a device may be listed more than once.  Calls on a
+ * group are serialised by the caller.  host_* pointers are host memory; host_logits
+ * ([B,1000]) and host_top1 ([B], first maximum wins as main.cu:243-249) may each be NULL. */
+typedef struct rn_shard rn_shard;
+RN_API void rn_shard_bounds(uint64_t B, int rank, int world, uint64_t *lo, uint64_t *hi);
+RN_API int rn_shard_create(rn_shard **out, const int *devices, int n_devices, int arch);
+RN_API int rn_shard_destroy(rn_shard *g);
+RN_API int rn_shard_count(const rn_shard *g);
+RN_API const char *rn_shard_last_error(const rn_shard *g);
+RN_API int rn_shard_set_tensor(rn_shard *g, const char *key, const float *host_data, uint64_t numel);
+RN_API int rn_shard_load_dir(rn_shard *g, const char *weights_dir);
+RN_API int rn_shard_set_dtype(rn_shard *g, int dtype);
+RN_API int rn_shard_finalize(rn_shard *g);
+RN_API int rn_shard_forward(rn_shard *g, const float *host_input_nchw, uint64_t B,
+                            float *host_logits, uint64_t *host_top1, int mode);
+/* rn_model_tune on every shard, at the batch size each shard sees for a batch of B */
+RN_API int rn_shard_tune(rn_shard *g, const float *host_input_nchw, uint64_t B, int mode);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,6 @@ from .tensor import Device, Shape, Tensor, FloatTensor, Context, get_ctx, set_de
 from .nn import (Conv2d, BatchNorm2d, Pool2d, Linear, reluForward, addForward,  # noqa: F401
                  convOutputSize)
 from .model import (ResnetModel, createResnet, createResnet152, layerForward,  # noqa: F401
-                    resnetForward, NativeModel, Pipeline, Graph)
+                    resnetForward, NativeModel, Pipeline, Graph, ShardedModel)
 
 __version__ = "0.1.0"

@@ -41,6 +41,8 @@ SIGNATURES = {
     "rn_ctx_set_layout": (c_int, [c_void_p, c_int]),
     "rn_ctx_get_layout": (c_int, [c_void_p]),
     "rn_ctx_set_sync_each_op": (c_int, [c_void_p, c_int]),
+    "rn_ctx_set_weight_cache": (c_int, [c_void_p, c_int]),
+    "rn_ctx_launch_count": (u64, [c_void_p]),
     "rn_conv_tile_candidates": (c_int, []),
     "rn_ctx_set_conv_tile": (c_int, [c_void_p, c_int]),
     "rn_ctx_set_split_k": (c_int, [c_void_p, c_int]),
@@ -124,6 +126,17 @@ SIGNATURES = {
     "rn_pipeline_submit": (c_int, [c_void_p, c_void_p]),
     "rn_pipeline_collect": (c_int, [c_void_p, c_void_p]),
     "rn_pipeline_in_flight": (u64, [c_void_p]),
+    "rn_shard_bounds": (None, [u64, c_int, c_int, POINTER(u64), POINTER(u64)]),
+    "rn_shard_create": (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, c_int]),
+    "rn_shard_destroy": (c_int, [c_void_p]),
+    "rn_shard_count": (c_int, [c_void_p]),
+    "rn_shard_last_error": (c_char_p, [c_void_p]),
+    "rn_shard_set_tensor": (c_int, [c_void_p, c_char_p, c_void_p, u64]),
+    "rn_shard_load_dir": (c_int, [c_void_p, c_char_p]),
+    "rn_shard_set_dtype": (c_int, [c_void_p, c_int]),
+    "rn_shard_finalize": (c_int, [c_void_p]),
+    "rn_shard_forward": (c_int, [c_void_p, c_void_p, u64, c_void_p, c_void_p, c_int]),
+    "rn_shard_tune": (c_int, [c_void_p, c_void_p, u64, c_int]),
 }
 
 _lib = None

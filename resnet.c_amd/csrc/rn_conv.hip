@@ -14,9 +14,10 @@
 //    when the tap falls into the padding (the reference skips those taps,
 //    ops.cu:35-37);
 //  * weights are pre-packed K-major [Cout][kh][kw][Cin] so B rows are 128-byte reads;
-//  * the 3-channel stem reads a zero-padded 4-channel image: one K segment is then
-//    8 (fp32) or 16 (bf16) consecutive pixels of one input row (unused kw slots and
-//    channel 3 carry zero weights), which turns the 7x7 stem into 7 K tiles;
+//  * the 3-channel stem reads a zero-padded 4-channel image: one K segment is then 8
+//    consecutive pixels of one input row (fp32: 7 K tiles for the 7x7 stem) or of each of
+//    two consecutive rows (bf16: 4 K tiles); unused kw / kh slots and channel 3 carry zero
+//    weights;
 //  * fp32: v_mfma_f32_32x32x2_f32 -- exact fp32 products and sums (bitwise an fmaf
 //    chain in k order), 256 FLOP/clk/CU = the 157 TFLOP/s fp32 roof of the chip;
 //    bf16 storage: v_mfma_f32_32x32x16_bf16 on the same 128-byte LDS rows;
@@ -221,13 +222,24 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
                 const int ow = rem - oh * p.Wo;
                 const int ih0 = oh * p.stride - p.pad;
                 const int iw0 = ow * p.stride - p.pad;
-                const int iwc = iw0 + c * p.chunk_dw;
-                a_off[j] = (((b * p.H + ih0) * p.W + iw0) * p.Cs + (XK ? 0 : c * CH)) * ES;
-                const int rlo = max(0, -ih0), rhi = min(p.KH, p.H - ih0);
+                // small-Cin forms: this thread's chunk is pixel(s) cc*chunk_dw.. of kernel row
+                // tap_rows*t + hi of K tile t
+                const int hi = p.tap_rows == 2 ? c >> 2 : 0, cc = p.tap_rows == 2 ? c & 3 : c;
+                const int iwc = iw0 + cc * p.chunk_dw;
+                a_off[j] = (((b * p.H + ih0 + hi) * p.W + iw0) * p.Cs + (XK ? 0 : cc * CH)) * ES;
+                int rm = 0;
+                if (p.tap_rows == 1) {
+                    const int rlo = max(0, -ih0), rhi = min(p.KH, p.H - ih0);
+                    rm = rhi > rlo ? ((1 << rhi) - 1) & ~((1 << rlo) - 1) : 0;
+                } else {
+                    for (int tt = 0; tt < p.KH; ++tt) {
+                        const int kh = p.tap_rows * tt + hi, row = ih0 + kh;
+                        if (kh < p.k_rows && row >= 0 && row < p.H) rm |= 1 << tt;
+                    }
+                }
                 const int clo = max(0, -iwc), chi = min(p.KW, p.W - iwc);
-                const int rm = rhi > rlo ? ((1 << rhi) - 1) & ~((1 << rlo) - 1) : 0;
                 int cm = chi > clo ? ((1 << chi) - 1) & ~((1 << clo) - 1) : 0;
-                if (p.chunk_dw && c >= p.c4_chunks) cm = 0;  // chunk holds only zero-weight slots
+                if (p.chunk_dw && cc >= p.c4_chunks) cm = 0;  // chunk holds only zero-weight slots
                 a_mask[j] = rm | (cm << 16);
                 if constexpr (DUAL)
                     a_off2[j] = (((b * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.Cs2 + c * CH) * ES;
@@ -296,7 +308,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
             if (first || s_cs == 0) {
                 const unsigned ukh = p.KW == 1 ? tap : (__umulhi(tap, p.mul_kw) >> p.shr_kw);
                 const int s_kh = (int)ukh, s_kw = (int)(tap - ukh * (unsigned)p.KW);
-                const int toff = (s_kh * p.W + s_kw) * p.Cs * ES;
+                const int toff = (s_kh * p.tap_rows * p.W + s_kw) * p.Cs * ES;
 #pragma unroll
                 for (int j = 0; j < AP; ++j) {
                     const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
@@ -755,20 +767,24 @@ void fast_div(unsigned d, unsigned *mul, unsigned *shr)
     *shr = p - 32;
 }
 
-// Blocks of one instantiation that fit a CU at once (registers and LDS), asked once.
+// Blocks of one instantiation that fit a CU at once (registers and LDS) on the context's device,
+// asked once per context and instantiation: the answer lives in the context, not in the process.
 template <typename T, typename TO, int BM, int BN, bool DUAL, bool XK, bool CHUNK>
-int resident_blocks_per_cu()
+int resident_blocks_per_cu(rn_ctx *ctx)
 {
-    static int cached = 0;
-    if (cached == 0) {
+    constexpr int tile = (BM == 128 ? 0 : 2) + (BN == 128 ? 0 : 1);
+    constexpr int types = sizeof(T) == 4 ? 0 : sizeof(TO) == 4 ? 1 : 2;
+    constexpr int id = tile + 4 * ((DUAL ? 1 : 0) + 2 * (XK ? 1 : 0) + 4 * (CHUNK ? 1 : 0)) + 32 * types;
+    static_assert(id < (int)(sizeof(ctx->occupancy) / sizeof(ctx->occupancy[0])), "occupancy table");
+    if (ctx->occupancy[id] == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_gemm_kernel<T, TO, BM, BN, DUAL, XK, CHUNK>, 256,
                                                          0) != hipSuccess ||
             nb < 1)
             nb = 1;
-        cached = nb;
+        ctx->occupancy[id] = nb;
     }
-    return cached;
+    return ctx->occupancy[id];
 }
 
 template <typename T, typename TO, int BM, int BN, bool DUAL, bool XK, bool CHUNK = false>
@@ -776,7 +792,7 @@ void launch_one(rn_ctx *ctx, GemmParams &p, bool persistent)
 {
     unsigned grid = p.grid_items;
     if (persistent) {
-        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN, DUAL, XK, CHUNK>();
+        const unsigned slots = 256u * (unsigned)resident_blocks_per_cu<T, TO, BM, BN, DUAL, XK, CHUNK>(ctx);
         if (grid > slots) grid = slots;
     }
     conv_gemm_kernel<T, TO, BM, BN, DUAL, XK, CHUNK><<<dim3(grid), dim3(256), 0, ctx->stream>>>(p);
@@ -831,13 +847,16 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     p.Ho = (int)h_out;
     p.Wo = (int)w_out;
     p.Cout = (int)Cout;
-    p.KH = (int)k;
+    const bool c4pair = c4 && dt_in == RN_DTYPE_BF16;  // two kernel rows per K tile
+    p.tap_rows = c4pair ? 2 : 1;
+    p.k_rows = (int)k;
+    p.KH = c4pair ? (int)rn_ceil_div(k, 2) : (int)k;
     p.KW = c4 ? 1 : (int)k;
     p.stride = (int)stride;
     p.pad = (int)pad;
     p.cseg = c4 ? 1 : (int)(Cin / bke);
     p.chunk_dw = c4 ? 16 / (4 * es) : 0;  // pixels of a 4-channel image per 16-byte chunk
-    p.c4_chunks = c4 ? (int)rn_ceil_div(k, p.chunk_dw) : 0;
+    p.c4_chunks = c4 ? (int)rn_ceil_div(k, p.chunk_dw) : 0;  // <= 4 in the two-row form (k <= 8)
     p.M = (int)(B * h_out * w_out);
     p.nk = p.KH * p.KW * p.cseg;
     p.nk1 = p.nk;
@@ -1161,7 +1180,7 @@ int rn_conv2d_nhwc_forward(rn_ctx *ctx, const float *inp, float *out, const floa
                            uint64_t w_out, uint64_t B, uint64_t in_channels, uint64_t out_channels,
                            uint64_t H, uint64_t W, const rn_epilogue *epilogue)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (B * out_channels * h_out * w_out == 0) return RN_OK;
     RN_TRY(check_conv_args(ctx, inp, out, packed_weight, kernel_size, stride, padding, h_out, w_out,
                            B, in_channels, out_channels, H, W));
@@ -1188,7 +1207,7 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
                       uint64_t w_out, uint64_t B, uint64_t in_channels, uint64_t out_channels,
                       uint64_t H, uint64_t W)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (B * out_channels * h_out * w_out == 0) return RN_OK;
     RN_TRY(check_conv_args(ctx, inp, out, weight, kernel_size, stride, padding, h_out, w_out, B,
                            in_channels, out_channels, H, W));
@@ -1206,10 +1225,18 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
                              ctx->layout == RN_LAYOUT_NHWC, 0, nullptr,
                              "rn_conv2d_forward(direct)");
     }
+    // K-major panel of the OIHW weight: packed per call into scratch, or -- with the context's
+    // weight cache on -- once per (weight buffer, shape) and kept until that buffer is freed or
+    // written through the rn_* calls
     const uint64_t wn = rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size);
-    void *wp = nullptr;
-    RN_TRY(rn_scratch(ctx, 1, wn * sizeof(float), &wp));
-    RN_TRY(rn_conv2d_pack_weight(ctx, weight, (float *)wp, in_channels, out_channels, kernel_size));
+    void *wp = ctx->wcache_on ? rn_wcache_find(ctx, weight, in_channels, out_channels, kernel_size) : nullptr;
+    if (!wp) {
+        if (ctx->wcache_on)
+            RN_TRY(rn_wcache_add(ctx, weight, in_channels, out_channels, kernel_size, wn * sizeof(float), &wp));
+        else
+            RN_TRY(rn_scratch(ctx, 1, wn * sizeof(float), &wp));
+        RN_TRY(rn_conv2d_pack_weight(ctx, weight, (float *)wp, in_channels, out_channels, kernel_size));
+    }
     if (ctx->layout == RN_LAYOUT_NHWC) {
         return launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, inp, out, wp, kernel_size, stride,
                            padding, h_out, w_out, B, in_channels, out_channels, H, W, nullptr,
@@ -1237,7 +1264,7 @@ int rn_conv2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void 
                               uint64_t in_channels, uint64_t out_channels, uint64_t H, uint64_t W,
                               const rn_epilogue *epilogue)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (dtype == RN_DTYPE_F32) {
         RN_REQUIRE(ctx, out_dtype == RN_DTYPE_F32, "fp32 input implies fp32 output");
         return rn_conv2d_nhwc_forward(ctx, (const float *)inp, (float *)out,
@@ -1261,7 +1288,7 @@ int rn_conv2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void 
                             "bf16 convolution needs in_channels %% 64 == 0 (got %llu)",
                             (unsigned long long)in_channels);
     }
-    const uint64_t ktot = c4 ? kernel_size * 64 : kernel_size * kernel_size * in_channels;
+    const uint64_t ktot = c4 ? rn_ceil_div(kernel_size, 2) * 64 : kernel_size * kernel_size * in_channels;
     RN_REQUIRE(ctx, B * H * W * cs < (1ull << 30) && out_channels * ktot < (1ull << 30) &&
                         B * h_out * w_out * out_channels < (1ull << 29),
                "tensor too large");
@@ -1279,7 +1306,7 @@ int rn_conv2d_nhwc_exact_forward(rn_ctx *ctx, const float *inp_padded, float *ou
                                  uint64_t in_channels, uint64_t out_channels, uint64_t Hp,
                                  uint64_t Wp, const rn_epilogue *epilogue)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (B * out_channels * h_out * w_out == 0) return RN_OK;
     RN_REQUIRE(ctx, inp_padded && out && packed_exact_weight && inp_padded != out,
                "null or aliased tensor");
@@ -1313,7 +1340,7 @@ int rn_conv2d_nhwc_pair_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const 
                                    uint64_t out_channels, uint64_t H, uint64_t W,
                                    const rn_conv_second *second, const rn_epilogue *epilogue)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     RN_REQUIRE(ctx, second && second->inp, "second source missing");
     RN_REQUIRE(ctx, dtype == RN_DTYPE_F32 || dtype == RN_DTYPE_BF16, "unknown dtype");
     RN_REQUIRE(ctx, out_dtype == dtype, "the fused pair keeps one element type");
@@ -1356,7 +1383,7 @@ int rn_conv2d_nhwc_pair_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const 
 int rn_linear_forward(rn_ctx *ctx, const float *inp, float *out, const float *weight,
                       const float *bias, uint64_t B, uint64_t in_features, uint64_t out_features)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (B * out_features == 0) return RN_OK;
     RN_REQUIRE(ctx, inp && out && weight, "null tensor");
     RN_REQUIRE(ctx, inp != out, "linear cannot run in place");

@@ -25,6 +25,10 @@ struct GemmParams {
     int cseg;       // 128-byte segments per tap
     int chunk_dw;   // small-Cin form: pixels per 16-byte chunk (0 otherwise)
     int c4_chunks;  // small-Cin form: chunks of a segment that carry real taps
+    // small-Cin form, bf16: a K tile holds tap_rows = 2 kernel rows (chunks 0-3: row 2t, chunks
+    // 4-7: row 2t+1, two 4-channel pixels per chunk), KH = ceil(k / 2) K tiles; k_rows = k, the
+    // kernel rows that exist.  Everywhere else tap_rows = 1 and k_rows = KH.
+    int tap_rows, k_rows;
     int M;          // B * Ho * Wo
     int Ktot;       // packed weight row length in elements
     int nk;         // K tiles

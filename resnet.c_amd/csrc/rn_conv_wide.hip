@@ -82,6 +82,11 @@ __device__ __forceinline__ void stamp(unsigned long long *buf, int slot)
     if (buf && threadIdx.x == 0) buf[(size_t)blockIdx.x * 16 + slot] = wall_clock64();
 }
 
+__device__ __forceinline__ void stamp_cycles(unsigned long long *buf, int slot)
+{
+    if (buf && threadIdx.x == 0) buf[(size_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memtime();
+}
+
 template <typename TO>
 struct Out;
 template <>
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
             if (s_cs == 0) {
                 const unsigned ukh = p.KW == 1 ? tap : (__umulhi(tap, p.mul_kw) >> p.shr_kw);
                 const int s_kh = (int)ukh, s_kw = (int)(tap - ukh * (unsigned)p.KW);
-                const int toff = (s_kh * p.W + s_kw) * p.Cs * 2;
+                const int toff = (s_kh * p.W + s_kw) * p.Cs * 2;  // tap_rows == 1 (eligibility)
 #pragma unroll
                 for (int j = 0; j < PA; ++j) {
                     const bool ok = ((a_mask[j] >> s_kh) & (a_mask[j] >> (16 + s_kw)) & 1) != 0;
@@ -282,7 +287,10 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
             wait_and_barrier<SB == 3 ? PA + PB : PA>();
         else
             wait_and_barrier<0>();
-        if (kt == 0) stamp(p.stamps, 1);
+        if (kt == 0) {
+            stamp(p.stamps, 1);
+            stamp_cycles(p.stamps, 8);
+        }
         // every wave is past its reads of tile kt-1: its slots take the tiles after next
         if constexpr (SB == 3) {
             if (kt + 2 < nk) {
@@ -299,6 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
         sb = sb == SB - 1 ? 0 : sb + 1;
     }
     wait_and_barrier<0>();  // every wave is done with the rings: they become the C staging area
+    stamp_cycles(p.stamps, 9);
     stamp(p.stamps, 2);
 
     // ---- epilogue ----------------------------------------------------------------------------
@@ -377,7 +386,11 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
         }
         if (pass + 1 < CPASS) __syncthreads();
     }
-    stamp(p.stamps, 3);
+    if (p.stamps) {
+        stamp(p.stamps, 3);  // epilogue stores issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(p.stamps, 4);  // ... and acknowledged
+    }
 }
 
 struct WideTile {

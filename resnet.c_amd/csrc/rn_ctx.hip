@@ -27,6 +27,7 @@ int rn_check_hip(rn_ctx *ctx, hipError_t e, const char *what)
 
 int rn_after_launch(rn_ctx *ctx, const char *what)
 {
+    ++ctx->launches;
     RN_TRY(rn_check_hip(ctx, hipGetLastError(), what));
     if (ctx->sync_each_op) {
         RN_TRY(rn_check_hip(ctx, hipStreamSynchronize(ctx->stream), what));
@@ -53,6 +54,60 @@ int rn_scratch(rn_ctx *ctx, int slot, uint64_t bytes, void **ptr)
     }
     *ptr = ctx->scratch[slot];
     return RN_OK;
+}
+
+void *rn_wcache_find(rn_ctx *ctx, const void *weight, uint64_t cin, uint64_t cout, uint64_t k)
+{
+    for (int i = 0; i < ctx->wcache_n; ++i) {
+        const rn_wcache_entry &e = ctx->wcache[i];
+        if (e.key == weight && e.cin == cin && e.cout == cout && e.k == k) return e.packed;
+    }
+    return nullptr;
+}
+
+int rn_wcache_add(rn_ctx *ctx, const void *weight, uint64_t cin, uint64_t cout, uint64_t k,
+                  uint64_t bytes, void **packed)
+{
+    if (ctx->wcache_n == ctx->wcache_cap) {
+        const int ncap = ctx->wcache_cap ? 2 * ctx->wcache_cap : 64;
+        rn_wcache_entry *ne = (rn_wcache_entry *)realloc(ctx->wcache, (size_t)ncap * sizeof(rn_wcache_entry));
+        if (!ne) return rn_set_error(ctx, RN_ERR_NOMEM, "weight cache table");
+        ctx->wcache = ne;
+        ctx->wcache_cap = ncap;
+    }
+    void *p = nullptr;
+    RN_HIP_TRY(ctx, hipMalloc(&p, bytes));
+    rn_wcache_entry &e = ctx->wcache[ctx->wcache_n++];
+    e.key = weight;
+    e.cin = cin;
+    e.cout = cout;
+    e.k = k;
+    e.packed = p;
+    *packed = p;
+    return RN_OK;
+}
+
+void rn_wcache_drop(rn_ctx *ctx, const void *lo, uint64_t bytes)
+{
+    const uintptr_t a = (uintptr_t)lo, b = a + (bytes ? bytes : 1);
+    int kept = 0, dropped = 0;
+    for (int i = 0; i < ctx->wcache_n; ++i) {
+        const uintptr_t key = (uintptr_t)ctx->wcache[i].key;
+        if (key >= a && key < b) {
+            if (!dropped++) (void)hipStreamSynchronize(ctx->stream);  // a queued launch may read it
+            (void)hipFree(ctx->wcache[i].packed);
+        } else {
+            ctx->wcache[kept++] = ctx->wcache[i];
+        }
+    }
+    ctx->wcache_n = kept;
+}
+
+int rn_bind_device(rn_ctx *ctx)
+{
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == ctx->device) return RN_OK;
+    return rn_check_hip(ctx, hipSetDevice(ctx->device), "hipSetDevice");
 }
 
 extern "C" {
@@ -117,6 +172,8 @@ int rn_ctx_destroy(rn_ctx *ctx)
     for (int i = 0; i < 5; ++i) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     }
+    for (int i = 0; i < ctx->wcache_n; ++i) (void)hipFree(ctx->wcache[i].packed);
+    free(ctx->wcache);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     free(ctx);
     return RN_OK;
@@ -163,6 +220,19 @@ int rn_ctx_set_split_k(rn_ctx *ctx, int max_splits)
     return RN_OK;
 }
 
+uint64_t rn_ctx_launch_count(const rn_ctx *ctx) { return ctx ? ctx->launches : 0; }
+
+int rn_ctx_set_weight_cache(rn_ctx *ctx, int on)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    ctx->wcache_on = on ? 1 : 0;
+    if (!on && ctx->wcache_n) {
+        RN_TRY(rn_bind_device(ctx));
+        rn_wcache_drop(ctx, nullptr, ~(uint64_t)0);
+    }
+    return RN_OK;
+}
+
 int rn_ctx_set_debug_stamps(rn_ctx *ctx, void *dev_buffer)
 {
     if (!ctx) return RN_ERR_INVALID;
@@ -176,6 +246,7 @@ int rn_ctx_device(const rn_ctx *ctx) { return ctx ? ctx->device : -1; }
 int rn_sync(rn_ctx *ctx)
 {
     if (!ctx) return RN_ERR_INVALID;
+    RN_TRY(rn_bind_device(ctx));
     RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     RN_HIP_TRY(ctx, hipGetLastError());
     return RN_OK;
@@ -188,7 +259,7 @@ int rn_malloc(rn_ctx *ctx, void **dev_ptr, uint64_t bytes)
     if (!ctx || !dev_ptr) return RN_ERR_INVALID;
     *dev_ptr = nullptr;
     if (bytes == 0) return RN_OK;  // empty tensor: null data (tensor.cuh:62-65)
-    RN_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RN_TRY(rn_bind_device(ctx));
     hipError_t e = hipMalloc(dev_ptr, bytes);
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
@@ -201,8 +272,17 @@ int rn_malloc(rn_ctx *ctx, void **dev_ptr, uint64_t bytes)
 int rn_free(rn_ctx *ctx, void *dev_ptr)
 {
     if (!ctx) return RN_ERR_INVALID;
+    RN_TRY(rn_bind_device(ctx));
     if (!dev_ptr) return RN_OK;
     RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->wcache_n) {  // panels packed from weights inside this allocation are stale now
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, dev_ptr) == hipSuccess)
+            rn_wcache_drop(ctx, base, size);
+        else
+            (void)hipGetLastError(), rn_wcache_drop(ctx, dev_ptr, 1);
+    }
     RN_HIP_TRY(ctx, hipFree(dev_ptr));
     return RN_OK;
 }
@@ -210,7 +290,9 @@ int rn_free(rn_ctx *ctx, void *dev_ptr)
 int rn_memcpy_h2d(rn_ctx *ctx, void *dev_dst, const void *host_src, uint64_t bytes)
 {
     if (!ctx || (bytes && (!dev_dst || !host_src))) return RN_ERR_INVALID;
+    RN_TRY(rn_bind_device(ctx));
     if (!bytes) return RN_OK;
+    if (ctx->wcache_n) rn_wcache_drop(ctx, dev_dst, bytes);
     RN_HIP_TRY(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RN_OK;
@@ -219,6 +301,7 @@ int rn_memcpy_h2d(rn_ctx *ctx, void *dev_dst, const void *host_src, uint64_t byt
 int rn_memcpy_d2h(rn_ctx *ctx, void *host_dst, const void *dev_src, uint64_t bytes)
 {
     if (!ctx || (bytes && (!host_dst || !dev_src))) return RN_ERR_INVALID;
+    RN_TRY(rn_bind_device(ctx));
     if (!bytes) return RN_OK;
     RN_HIP_TRY(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -228,7 +311,9 @@ int rn_memcpy_d2h(rn_ctx *ctx, void *host_dst, const void *dev_src, uint64_t byt
 int rn_memcpy_d2d(rn_ctx *ctx, void *dev_dst, const void *dev_src, uint64_t bytes)
 {
     if (!ctx || (bytes && (!dev_dst || !dev_src))) return RN_ERR_INVALID;
+    RN_TRY(rn_bind_device(ctx));
     if (!bytes) return RN_OK;
+    if (ctx->wcache_n) rn_wcache_drop(ctx, dev_dst, bytes);
     RN_HIP_TRY(ctx,
                hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return RN_OK;
@@ -237,7 +322,9 @@ int rn_memcpy_d2d(rn_ctx *ctx, void *dev_dst, const void *dev_src, uint64_t byte
 int rn_memset(rn_ctx *ctx, void *dev_ptr, int byte_value, uint64_t bytes)
 {
     if (!ctx || (bytes && !dev_ptr)) return RN_ERR_INVALID;
+    RN_TRY(rn_bind_device(ctx));
     if (!bytes) return RN_OK;
+    if (ctx->wcache_n) rn_wcache_drop(ctx, dev_ptr, bytes);
     RN_HIP_TRY(ctx, hipMemsetAsync(dev_ptr, byte_value, bytes, ctx->stream));
     return RN_OK;
 }
@@ -307,6 +394,7 @@ int rn_save_f32_file(rn_ctx *ctx, const char *path, const float *dev_ptr, uint64
 int rn_event_create(rn_ctx *ctx, rn_event **out)
 {
     if (!ctx || !out) return RN_ERR_INVALID;
+    RN_TRY(rn_bind_device(ctx));
     rn_event *ev = (rn_event *)calloc(1, sizeof(rn_event));
     if (!ev) return RN_ERR_NOMEM;
     int st = rn_check_hip(ctx, hipEventCreate(&ev->ev), "hipEventCreate");
@@ -329,6 +417,7 @@ int rn_event_destroy(rn_event *ev)
 int rn_event_record(rn_ctx *ctx, rn_event *ev)
 {
     if (!ctx || !ev) return RN_ERR_INVALID;
+    RN_TRY(rn_bind_device(ctx));
     RN_HIP_TRY(ctx, hipEventRecord(ev->ev, ctx->stream));
     return RN_OK;
 }

@@ -257,7 +257,7 @@ extern "C" {
 
 int rn_relu_forward(rn_ctx *ctx, const float *inp, float *out, uint64_t N)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     RN_REQUIRE(ctx, N == 0 || (inp && out), "null tensor");
     if (N == 0) return RN_OK;
     if (aligned16(inp) && aligned16(out)) {
@@ -271,7 +271,7 @@ int rn_relu_forward(rn_ctx *ctx, const float *inp, float *out, uint64_t N)
 
 int rn_add_forward(rn_ctx *ctx, const float *inp1, const float *inp2, float *out, uint64_t N)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     RN_REQUIRE(ctx, N == 0 || (inp1 && inp2 && out), "null tensor");
     if (N == 0) return RN_OK;
     if (aligned16(inp1) && aligned16(inp2) && aligned16(out)) {
@@ -289,7 +289,7 @@ int rn_batchnorm2d_forward(rn_ctx *ctx, const float *inp, float *out, const floa
                            const float *bias, const float *mean, const float *var, uint64_t B,
                            uint64_t C, uint64_t N)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     const uint64_t total = B * C * N;
     if (total == 0) return RN_OK;
     RN_REQUIRE(ctx, inp && out && weight && bias && mean && var, "null tensor");
@@ -340,7 +340,7 @@ int rn_batchnorm2d_forward(rn_ctx *ctx, const float *inp, float *out, const floa
 int rn_batchnorm2d_fold(rn_ctx *ctx, const float *weight, const float *bias, const float *mean,
                         const float *var, float *scale, float *shift, uint64_t C)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (C == 0) return RN_OK;
     RN_REQUIRE(ctx, weight && bias && mean && var && scale && shift, "null tensor");
     bn_fold_kernel<<<(unsigned)rn_ceil_div(C, 256), 256, 0, ctx->stream>>>(weight, bias, mean, var,
@@ -351,7 +351,7 @@ int rn_batchnorm2d_fold(rn_ctx *ctx, const float *weight, const float *bias, con
 int rn_argmax_forward(rn_ctx *ctx, const float *logits, uint64_t *idx, uint64_t B,
                       uint64_t classes)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (B == 0) return RN_OK;
     RN_REQUIRE(ctx, logits && idx && classes > 0, "null tensor or zero classes");
     RN_REQUIRE(ctx, B < (1ull << 31), "batch too large");

@@ -5,7 +5,11 @@
  * B = 1, paths); here the same defaults can be overridden from the command line.
  *
  *   rn_infer [--arch 50|101|152] [--weights DIR] [--input FILE] [--batch B]
- *            [--mode fused|ops] [--device N]
+ *            [--mode fused|ops] [--device N | --devices a,b,c,...]
+ *
+ * --devices shards the batch contiguously over the listed devices (rn_shard_*: one host
+ * thread + context + model per device, no data moves between devices) and prints the class
+ * indices in image order, exactly as the single-device run does.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,9 +27,52 @@
         }                                                                                 \
     } while (0)
 
+static int run_sharded(const int *devices, int ndev, int arch, const char *weights,
+                       const char *input, uint64_t B, int mode)
+{
+    rn_shard *g = NULL;
+    float *host = NULL;
+    uint64_t *idx = NULL, b;
+    const uint64_t want = B * 3 * 224 * 224;
+    FILE *f;
+    int st;
+    st = rn_shard_create(&g, devices, ndev, arch);
+    if (st != RN_OK) { fprintf(stderr, "rn_infer: rn_shard_create: %s\n", rn_status_string(st)); return 1; }
+#define SCHECK(expr)                                                                         \
+    do {                                                                                     \
+        int st_ = (expr);                                                                    \
+        if (st_ != RN_OK) {                                                                  \
+            fprintf(stderr, "rn_infer: %s failed: %s (%s)\n", #expr, rn_status_string(st_),  \
+                    rn_shard_last_error(g));                                                 \
+            return 1;                                                                        \
+        }                                                                                    \
+    } while (0)
+    SCHECK(rn_shard_load_dir(g, weights));
+    SCHECK(rn_shard_finalize(g));
+    printf("created model\n");
+    host = (float *)malloc(want * sizeof(float));
+    idx = (uint64_t *)malloc(B * sizeof(uint64_t));
+    f = fopen(input, "rb");
+    if (!host || !idx || !f || fread(host, sizeof(float), want, f) != want || fgetc(f) != EOF) {
+        fprintf(stderr, "rn_infer: %s does not hold exactly %llu floats (batch %llu)\n", input,
+                (unsigned long long)want, (unsigned long long)B);
+        return 1;
+    }
+    fclose(f);
+    SCHECK(rn_shard_forward(g, host, B, NULL, idx, mode));
+#undef SCHECK
+    printf("Finished\n");
+    for (b = 0; b < B; ++b) printf("max index is %llu\n", (unsigned long long)idx[b]);
+    free(idx);
+    free(host);
+    rn_shard_destroy(g);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     int arch = 152, device = 0, mode = RN_FWD_FUSED, i;
+    int devices[64], ndev = 0;
     uint64_t B = 1, numel = 0, b;
     const char *weights = "weights_bin";
     const char *input = "test_bins/ILSVRC2012_val_00004749.bin";
@@ -42,14 +89,23 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--input") && v) { input = v; ++i; }
         else if (!strcmp(a, "--batch") && v) { B = strtoull(v, NULL, 10); ++i; }
         else if (!strcmp(a, "--device") && v) { device = atoi(v); ++i; }
+        else if (!strcmp(a, "--devices") && v) {
+            const char *q = v;
+            while (*q && ndev < 64) {
+                devices[ndev++] = (int)strtol(q, (char **)&q, 10);
+                if (*q == ',') ++q;
+            }
+            ++i;
+        }
         else if (!strcmp(a, "--mode") && v) { mode = strcmp(v, "ops") ? RN_FWD_FUSED : RN_FWD_REFERENCE_OPS; ++i; }
         else {
             fprintf(stderr, "usage: %s [--arch 50|101|152] [--weights DIR] [--input FILE] "
-                            "[--batch B] [--mode fused|ops] [--device N]\n", argv[0]);
+                            "[--batch B] [--mode fused|ops] [--device N | --devices a,b,...]\n", argv[0]);
             return 2;
         }
     }
     printf("Started\n");
+    if (ndev > 0) return run_sharded(devices, ndev, arch, weights, input, B, mode);
     CHECK(ctx, rn_ctx_create(&ctx, device, NULL));
     CHECK(ctx, rn_model_create(ctx, &model, arch));
     CHECK(ctx, rn_model_load_dir(model, weights));

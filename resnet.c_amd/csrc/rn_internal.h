@@ -8,6 +8,12 @@
 
 #include "rn_hip.h"
 
+struct rn_wcache_entry {
+    const void *key;  // the caller's OIHW weight buffer
+    uint64_t cin, cout, k;
+    void *packed;
+};
+
 struct rn_ctx {
     int device;
     hipStream_t stream;
@@ -22,6 +28,14 @@ struct rn_ctx {
     // warm up first so the sizes are already settled)
     void *scratch[5];  // 0 batch-norm constants, 1-3 NCHW convolution, 4 split-K partial sums
     uint64_t scratch_bytes[5];
+    // resident blocks per CU of each contraction-kernel instantiation on THIS context's device,
+    // asked once per context (0 = not asked yet); no process-wide mutable state
+    int occupancy[256];
+    uint64_t launches;  // kernel launches issued through this context (rn_after_launch)
+    // packed-weight cache of the NCHW drop-in route (rn_conv2d_forward): OIHW weight pointer +
+    // shape -> K-major panel, packed on first use; off unless rn_ctx_set_weight_cache(ctx, 1)
+    int wcache_on, wcache_n, wcache_cap;
+    struct rn_wcache_entry *wcache;
     char err[512];
 };
 
@@ -30,9 +44,19 @@ struct rn_event {
 };
 
 int rn_set_error(rn_ctx *ctx, int status, const char *fmt, ...);
+// make the context's device the calling thread's current device (a host thread may own
+// contexts on several devices; a launch on the wrong current device would fail or, worse, run
+// elsewhere).  Every entry point that touches the device starts with RN_ENTER.
+int rn_bind_device(rn_ctx *ctx);
 int rn_check_hip(rn_ctx *ctx, hipError_t e, const char *what);
 // scratch slot `slot` with at least `bytes`; contents undefined
 int rn_scratch(rn_ctx *ctx, int slot, uint64_t bytes, void **ptr);
+// packed-weight cache: the panel for (weight, shape), or null; add = allocate an entry's panel
+// (the caller packs into it); drop = forget every entry whose key lies in [lo, lo + bytes)
+void *rn_wcache_find(rn_ctx *ctx, const void *weight, uint64_t cin, uint64_t cout, uint64_t k);
+int rn_wcache_add(rn_ctx *ctx, const void *weight, uint64_t cin, uint64_t cout, uint64_t k,
+                  uint64_t bytes, void **packed);
+void rn_wcache_drop(rn_ctx *ctx, const void *lo, uint64_t bytes);
 // launch epilogue shared by every op: launch-error check and optional per-op sync
 int rn_after_launch(rn_ctx *ctx, const char *what);
 
@@ -40,6 +64,13 @@ int rn_after_launch(rn_ctx *ctx, const char *what);
     do {                                                       \
         int rn_st_ = rn_check_hip((ctx), (expr), #expr);       \
         if (rn_st_ != RN_OK) return rn_st_;                    \
+    } while (0)
+
+#define RN_ENTER(ctx)                                  \
+    do {                                               \
+        if (!(ctx)) return RN_ERR_INVALID;             \
+        int rn_en_ = rn_bind_device(ctx);              \
+        if (rn_en_ != RN_OK) return rn_en_;            \
     } while (0)
 
 #define RN_TRY(expr)                       \

@@ -163,21 +163,24 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float *__re
     }
 }
 
-// small-Cin bf16 panel: [Cout][kh][16 kw slots][4 channel slots] (one 128-byte K segment
-// = 16 consecutive pixels of a 4-channel bf16 image)
+// small-Cin bf16 panel: [Cout][ceil(k/2)][2 kernel rows][8 kw slots][4 channel slots]: one
+// 128-byte K segment = 8 consecutive pixels of a 4-channel bf16 image in each of two
+// consecutive image rows (kernel rows 2t and 2t+1); zero where kh >= k, kw >= k or ic >= Cin
 __global__ __launch_bounds__(256) void pack_weight_c4_bf16_kernel(const float *__restrict__ w,
                                                                   bf16_t *__restrict__ packed,
                                                                   uint32_t Cin, uint32_t k,
                                                                   uint64_t total)
 {
     const uint64_t gstride = (uint64_t)gridDim.x * 256;
+    const uint32_t kt = (k + 1) / 2;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += gstride) {
         const uint32_t ic = (uint32_t)(i & 3);
-        const uint32_t kw = (uint32_t)((i >> 2) & 15);
+        const uint32_t kw = (uint32_t)((i >> 2) & 7);
+        const uint32_t hi = (uint32_t)((i >> 5) & 1);
         const uint64_t r = i >> 6;
-        const uint32_t kh = (uint32_t)(r % k);
-        const uint64_t oc = r / k;
-        packed[i] = (bf16_t)((ic < Cin && kw < k) ? w[((oc * Cin + ic) * k + kh) * k + kw] : 0.f);
+        const uint32_t kh = 2 * (uint32_t)(r % kt) + hi;
+        const uint64_t oc = r / kt;
+        packed[i] = (bf16_t)((ic < Cin && kw < k && kh < k) ? w[((oc * Cin + ic) * k + kh) * k + kw] : 0.f);
     }
 }
 
@@ -282,7 +285,7 @@ uint64_t rn_conv2d_packed_weight_numel(uint64_t in_channels, uint64_t out_channe
 int rn_conv2d_pack_weight(rn_ctx *ctx, const float *weight_oihw, float *packed,
                           uint64_t in_channels, uint64_t out_channels, uint64_t kernel_size)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     const uint64_t total = rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size);
     if (total == 0) return RN_OK;
     RN_REQUIRE(ctx, weight_oihw && packed && weight_oihw != packed, "null or aliased tensor");
@@ -306,7 +309,7 @@ uint64_t rn_conv2d_packed_weight_numel_exact(uint64_t in_channels, uint64_t out_
 int rn_conv2d_pack_weight_exact(rn_ctx *ctx, const float *weight_oihw, float *packed,
                                 uint64_t in_channels, uint64_t out_channels, uint64_t kernel_size)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     const uint64_t total =
         rn_conv2d_packed_weight_numel_exact(in_channels, out_channels, kernel_size);
     if (total == 0) return RN_OK;
@@ -330,7 +333,7 @@ int rn_conv2d_pack_weight_pair_dt(rn_ctx *ctx, int dtype, const float *w1_oihw, 
                                   uint64_t in_channels, uint64_t out_channels, uint64_t kernel_size,
                                   uint64_t in_channels2)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     RN_REQUIRE(ctx, dtype == RN_DTYPE_F32 || dtype == RN_DTYPE_BF16, "unknown dtype");
     const uint64_t total =
         rn_conv2d_packed_pair_weight_numel(in_channels, out_channels, kernel_size, in_channels2);
@@ -356,14 +359,14 @@ uint64_t rn_conv2d_packed_weight_numel_dt(int dtype, uint64_t in_channels, uint6
 {
     if (dtype == RN_DTYPE_F32)
         return rn_conv2d_packed_weight_numel(in_channels, out_channels, kernel_size);
-    if (rn_conv_is_c4(in_channels, kernel_size)) return out_channels * kernel_size * 64;
+    if (rn_conv_is_c4(in_channels, kernel_size)) return out_channels * rn_ceil_div(kernel_size, 2) * 64;
     return out_channels * kernel_size * kernel_size * in_channels;
 }
 
 int rn_conv2d_pack_weight_dt(rn_ctx *ctx, int dtype, const float *weight_oihw, void *packed,
                              uint64_t in_channels, uint64_t out_channels, uint64_t kernel_size)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (dtype == RN_DTYPE_F32)
         return rn_conv2d_pack_weight(ctx, weight_oihw, (float *)packed, in_channels, out_channels,
                                      kernel_size);
@@ -386,7 +389,7 @@ int rn_conv2d_pack_weight_dt(rn_ctx *ctx, int dtype, const float *weight_oihw, v
 int rn_nchw_to_nhwc_pad_dt(rn_ctx *ctx, int dtype, const float *src, void *dst, uint64_t B,
                            uint64_t C, uint64_t H, uint64_t W, uint64_t Cpad, uint64_t border)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (dtype == RN_DTYPE_F32 && border == 0)
         return rn_nchw_to_nhwc_pad(ctx, src, (float *)dst, B, C, H, W, Cpad);
     const uint64_t total = B * (H + 2 * border) * (W + 2 * border) * Cpad;
@@ -458,21 +461,21 @@ static int transpose_launch(rn_ctx *ctx, const float *src, float *dst, uint64_t 
 int rn_nchw_to_nhwc(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t C, uint64_t H,
                     uint64_t W)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     return transpose_launch(ctx, src, dst, B, C, H * W, "rn_nchw_to_nhwc");
 }
 
 int rn_nhwc_to_nchw(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t C, uint64_t H,
                     uint64_t W)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     return transpose_launch(ctx, src, dst, B, H * W, C, "rn_nhwc_to_nchw");
 }
 
 int rn_nchw_to_nhwc_pad(rn_ctx *ctx, const float *src, float *dst, uint64_t B, uint64_t C,
                         uint64_t H, uint64_t W, uint64_t Cpad)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     const uint64_t HW = H * W;
     if (B * HW * Cpad == 0) return RN_OK;
     RN_REQUIRE(ctx, src && dst && src != dst, "null or aliased tensor");

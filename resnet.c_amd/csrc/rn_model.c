@@ -715,17 +715,13 @@ static int block_forward(rn_model *m, rn_block *b, const float *x, float *y, uin
     return RN_OK;
 }
 
-int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
+/* One sub-batch: every tensor of it stays below the kernels' 2^29-element range. */
+static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
 {
     const rn_conv *stem;
     uint64_t H = 224, W = 224, ho, wo, ph, pw;
     float *x, *y, *tmp;
     int bi, saved_layout, st;
-    if (!m || !input_nchw || !logits || B == 0) return RN_ERR_INVALID;
-    if (mode != RN_FWD_REFERENCE_OPS && mode != RN_FWD_FUSED) return RN_ERR_INVALID;
-    if (!m->finalized) return RN_ERR_INVALID;
-    /* bf16 storage exists only with the fused epilogues (no standalone bf16 bn/relu/add) */
-    if (m->dtype != RN_DTYPE_F32 && mode != RN_FWD_FUSED) return RN_ERR_UNSUPPORTED;
     TRY(ensure_acts(m, B));
     m->n_prof = 0;
     m->cur_mode = mode;
@@ -821,12 +817,37 @@ int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *lo
     return st;
 }
 
+/* The reference has no batch limit other than memory (main.cu:168-226).  Here the contraction
+ * kernels address every tensor with 32-bit byte offsets (2^29 fp32 elements; the stem output
+ * of 669 images is the first to pass it), so a larger batch runs as sub-batches of at most
+ * RN_MAX_SUB_BATCH images through the same arenas.  Every image's logits are independent of
+ * what else is in its launch (batch invariance, bit for bit), so the split changes nothing. */
+#define RN_MAX_SUB_BATCH 512
+
+int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
+{
+    uint64_t done = 0;
+    if (!m || !input_nchw || !logits || B == 0) return RN_ERR_INVALID;
+    if (mode != RN_FWD_REFERENCE_OPS && mode != RN_FWD_FUSED) return RN_ERR_INVALID;
+    if (!m->finalized) return RN_ERR_INVALID;
+    /* bf16 storage exists only with the fused epilogues (no standalone bf16 bn/relu/add) */
+    if (m->dtype != RN_DTYPE_F32 && mode != RN_FWD_FUSED) return RN_ERR_UNSUPPORTED;
+    while (done < B) {
+        const uint64_t nb = B - done < RN_MAX_SUB_BATCH ? B - done : RN_MAX_SUB_BATCH;
+        TRY(forward_chunk(m, input_nchw + done * 3 * 224 * 224, nb, logits + done * RN_CLASSES, mode));
+        done += nb;
+    }
+    return RN_OK;
+}
+
 int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
 {
     rn_event *e0 = NULL, *e1 = NULL;
     const int ncand = rn_conv_tile_candidates();
     int i, c, r, st;
+    const uint64_t B_all = B;
     if (!m) return RN_ERR_INVALID;
+    if (B > RN_MAX_SUB_BATCH) B = RN_MAX_SUB_BATCH; /* the launches of a larger batch are sub-batches */
     /* one recorded forward with the per-launch choice: fills the buffers with real data */
     m->tuned_B = 0;
     m->n_calls = 0;
@@ -889,5 +910,5 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
     m->tuned_B = B;
     m->tuned_mode = mode;
     /* leave the buffers and the logits as a normal forward would */
-    return rn_model_forward(m, input_nchw, B, logits, mode);
+    return rn_model_forward(m, input_nchw, B_all, logits, mode);
 }

@@ -57,6 +57,7 @@ int rn_model_capture(rn_model *m, const float *input_nchw, uint64_t B, float *lo
     if (!m || !out) return RN_ERR_INVALID;
     *out = nullptr;
     rn_ctx *ctx = rn_model_context(m);
+    RN_TRY(rn_bind_device(ctx));
     if (ctx->sync_each_op)
         return rn_set_error(ctx, RN_ERR_INVALID, "rn_model_capture: sync_each_op must be off");
     if (rn_model_profiling_enabled(m))
@@ -97,6 +98,7 @@ int rn_model_capture(rn_model *m, const float *input_nchw, uint64_t B, float *lo
 int rn_graph_launch(rn_graph *g)
 {
     if (!g) return RN_ERR_INVALID;
+    RN_TRY(rn_bind_device(g->ctx));
     RN_HIP_TRY(g->ctx, hipGraphLaunch(g->exec, g->ctx->stream));
     return RN_OK;
 }
@@ -170,6 +172,7 @@ int rn_pipeline_submit(rn_pipeline *p, const float *host_input_nchw)
 {
     if (!p) return RN_ERR_INVALID;
     rn_ctx *ctx = p->ctx;
+    RN_TRY(rn_bind_device(ctx));
     if (p->head - p->tail >= 2)
         return rn_set_error(ctx, RN_ERR_INVALID, "rn_pipeline_submit: both slots busy, collect first");
     rn_pipeline_slot *s = &p->slot[p->head & 1];

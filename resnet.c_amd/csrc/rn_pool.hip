@@ -200,7 +200,7 @@ int pool_dispatch(rn_ctx *ctx, const float *inp, float *out, uint64_t k, uint64_
                   uint64_t pad, uint64_t h_out, uint64_t w_out, uint64_t B, uint64_t C, uint64_t H,
                   uint64_t W, const char *what)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     const uint64_t total = B * C * h_out * w_out;
     if (total == 0) return RN_OK;
     RN_REQUIRE(ctx, inp && out, "null tensor");
@@ -240,7 +240,7 @@ int rn_maxpool2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, const void *inp, void *
                                  uint64_t h_out, uint64_t w_out, uint64_t B, uint64_t channels,
                                  uint64_t H, uint64_t W)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (dtype == RN_DTYPE_BF16)
         return pool_bf16_dispatch<true>(ctx, inp, out, kernel_size, stride, padding, h_out, w_out, B,
                                         channels, H, W, "rn_maxpool2d_nhwc_forward_dt");
@@ -258,7 +258,7 @@ int rn_avgpool2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, const void *inp, void *
                                  uint64_t h_out, uint64_t w_out, uint64_t B, uint64_t channels,
                                  uint64_t H, uint64_t W)
 {
-    if (!ctx) return RN_ERR_INVALID;
+    RN_ENTER(ctx);
     if (dtype == RN_DTYPE_BF16)
         return pool_bf16_dispatch<false>(ctx, inp, out, kernel_size, stride, padding, h_out, w_out,
                                          B, channels, H, W, "rn_avgpool2d_nhwc_forward_dt");

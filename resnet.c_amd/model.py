@@ -303,6 +303,75 @@ class NativeModel:
             pass
 
 
+class ShardedModel:
+    """One batch over several devices of a node (rn_shard_*): the multi-device form of the
+    reference's main() (main.cu:228-254).  Contiguous batch split, weights replicated, no data
+    moves between devices; one host thread + context + model per listed device inside the
+    library.  A device may be listed twice (how a one-GPU box exercises the sharding)."""
+
+    def __init__(self, devices, arch: str = "resnet50", state: Optional[Dict[str, np.ndarray]] = None,
+                 weights_dir: Optional[str] = None, dtype: str = "f32"):
+        lib = L.lib()
+        if (state is None) == (weights_dir is None):
+            raise ValueError("give exactly one of state / weights_dir")
+        dev = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        L.check(lib.rn_shard_create(ctypes.byref(h), dev, len(devices), ARCH_ID[arch]), "rn_shard_create")
+        self.handle, self.n = h, len(devices)
+        if weights_dir is not None:
+            self._check(lib.rn_shard_load_dir(h, weights_dir.encode()), "rn_shard_load_dir")
+        else:
+            for key, arr in state.items():
+                if key.endswith("num_batches_tracked"):
+                    continue
+                a = np.ascontiguousarray(arr, dtype=np.float32)
+                self._check(lib.rn_shard_set_tensor(h, key.encode(), a.ctypes.data, a.size),
+                            f"rn_shard_set_tensor({key})")
+        self._check(lib.rn_shard_set_dtype(h, {"f32": L.RN_DTYPE_F32, "bf16": L.RN_DTYPE_BF16}[dtype]),
+                    "rn_shard_set_dtype")
+        self._check(lib.rn_shard_finalize(h), "rn_shard_finalize")
+
+    def _check(self, status: int, where: str) -> None:
+        if status != L.RN_OK:
+            msg = L.lib().rn_shard_last_error(self.handle)
+            raise L.RnError(status, where, msg.decode() if msg else "")
+
+    @staticmethod
+    def bounds(B: int, rank: int, world: int) -> Tuple[int, int]:
+        lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+        L.lib().rn_shard_bounds(B, rank, world, ctypes.byref(lo), ctypes.byref(hi))
+        return lo.value, hi.value
+
+    def forward(self, x: np.ndarray, fused: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """NCHW host array -> (logits [B,1000], top-1 [B]) host arrays, image order."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        B = x.shape[0]
+        logits = np.empty((B, 1000), dtype=np.float32)
+        top1 = np.empty(B, dtype=np.uint64)
+        self._check(L.lib().rn_shard_forward(self.handle, x.ctypes.data, B, logits.ctypes.data,
+                                             top1.ctypes.data,
+                                             L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS),
+                    "rn_shard_forward")
+        return logits, top1
+
+    def tune(self, x: np.ndarray, fused: bool = True) -> None:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        self._check(L.lib().rn_shard_tune(self.handle, x.ctypes.data, x.shape[0],
+                                          L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS),
+                    "rn_shard_tune")
+
+    def close(self) -> None:
+        if self.handle:
+            L.lib().rn_shard_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Graph:
     """A captured forward (rn_model_capture): launch() replays it on the context's stream."""
 

@@ -67,6 +67,10 @@ class Context:
     def set_sync_each_op(self, on: bool) -> None:
         L.check(L.lib().rn_ctx_set_sync_each_op(self.handle, int(on)), "rn_ctx_set_sync_each_op")
 
+    def set_weight_cache(self, on: bool) -> None:
+        """rn_conv2d_forward (OIHW weights) packs each weight buffer once instead of per call."""
+        L.check(L.lib().rn_ctx_set_weight_cache(self.handle, int(on)), "rn_ctx_set_weight_cache")
+
     def set_split_k(self, max_splits: int) -> None:
         """Latency mode for small batches: split under-filled contractions along K."""
         L.check(L.lib().rn_ctx_set_split_k(self.handle, int(max_splits)), "rn_ctx_set_split_k",

@@ -136,3 +136,22 @@ def test_shape_and_cpu_tensor_mirror_reference_semantics(tmp_path):
     c = R.Tensor((0,), R.Device.CPU)
     c.move_from(b)
     assert c and not b and b.shape() == R.Shape((0,))
+
+
+def test_shard_bounds_of_the_c_driver_match_bench():
+    """rn_shard_bounds (the plain-C multi-device driver) and bench.shard_bounds (the
+    torch.distributed launch) split a batch the same way: contiguous, covering, in rank order."""
+    import ctypes
+
+    import bench
+    lib = L.lib()
+    for B in (1, 5, 7, 255, 256, 2048, 2049):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+                lib.rn_shard_bounds(B, r, world, ctypes.byref(lo), ctypes.byref(hi))
+                assert (lo.value, hi.value) == bench.shard_bounds(B, r, world)
+                assert lo.value == prev and hi.value - lo.value in (B // world, B // world + 1)
+                prev = hi.value
+            assert prev == B

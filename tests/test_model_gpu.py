@@ -181,6 +181,162 @@ def test_full_size_batch_properties(model50, finch):
     assert model50.activation_bytes() < 4 * 2**30
 
 
+def _full_size_properties(m, finch, B):
+    """Size-independent checks at a BASELINE.json batch size: the planted reference image and a
+    planted random image reproduce their batch-1 logits bit for bit (batch invariance is what
+    makes the sharded run equal to the whole one), duplicates give equal rows, two runs agree."""
+    x = R.weights.generate_input(B, seed=3 + B)
+    x[17] = finch[0]
+    x[B - 1] = x[0]
+    full = m.forward(x, fused=True)
+    assert full.shape == (B, 1000) and np.isfinite(full).all()
+    alone = m.forward(finch, fused=True)
+    assert np.array_equal(full[17:18], alone)
+    assert np.array_equal(full[B - 1], full[0])
+    assert np.array_equal(full[B // 2:B // 2 + 1], m.forward(x[B // 2:B // 2 + 1], fused=True))
+    assert np.array_equal(full, m.forward(x, fused=True))
+    return full, alone
+
+
+def test_full_size_resnet152_b128_properties(state152, finch, golden_dir):
+    """BASELINE.json configs[4]: ResNet-152 fp32 B=128 -- the cut-tail / chunked-K launch
+    geometry of this size, after a tuning pass as bench.py runs it."""
+    m = R.NativeModel("resnet152", state=state152)
+    try:
+        B = 128
+        _full_size_properties(m, finch, B)
+        x = R.weights.generate_input(B, seed=3 + B)
+        x[17] = finch[0]
+        x[B - 1] = x[0]
+        before = m.forward(x, fused=True)
+        xin = R.FloatTensor.from_numpy(x, R.Device.GPU)
+        out = R.FloatTensor((B, 1000), R.Device.GPU)
+        m.tune(xin.data(), B, out.data(), fused=True)
+        m.ctx.sync()
+        assert np.array_equal(out.numpy(), before)       # tuned tiles: same bits
+        want = np.load(os.path.join(golden_dir, "resnet152_finch_logits.npy"))
+        assert np.abs(before[17:18] - want).max() <= TOL   # and the reference module's logits
+        assert int(before[17].argmax()) == int(want.argmax(1)[0])
+    finally:
+        m.close()
+
+
+def test_full_size_resnet50_bf16_b256_properties(state50, model50, finch):
+    """BASELINE.json configs[3], one GPU's shard: ResNet-50 bf16 B=256, tuned as bench.py runs it
+    (the 256-wide LDS-DMA tiles are chosen at this size)."""
+    m = R.NativeModel("resnet50", state=state50, dtype="bf16")
+    try:
+        B = 256
+        full, alone = _full_size_properties(m, finch, B)
+        x = R.weights.generate_input(B, seed=3 + B)
+        x[17] = finch[0]
+        x[B - 1] = x[0]
+        xin = R.FloatTensor.from_numpy(x, R.Device.GPU)
+        out = R.FloatTensor((B, 1000), R.Device.GPU)
+        m.tune(xin.data(), B, out.data(), fused=True)
+        m.ctx.sync()
+        assert np.array_equal(out.numpy(), full)
+        assert np.array_equal(m.forward(x, fused=True), full)
+        # against the fp32 engine: same top-1 wherever the fp32 margin is not razor thin
+        f32 = model50.forward(x[:32], fused=True)
+        top2 = np.sort(f32, axis=1)[:, -2:]
+        clear = (top2[:, 1] - top2[:, 0]) > 0.2
+        assert clear.sum() >= 16
+        assert np.array_equal(full[:32].argmax(1)[clear], f32.argmax(1)[clear])
+        assert np.abs(full[:32] - f32).max() <= 0.25
+    finally:
+        m.close()
+
+
+def test_batch_larger_than_one_launch_can_address_runs_as_sub_batches(model50, finch):
+    """The reference has no batch limit but memory (main.cu:168-226).  The stem output of 669
+    fp32 images passes the kernels' 2^29-element range, so rn_model_forward runs B = 700 as
+    sub-batches of at most 512: every row equals its batch-1 bits, and the rate stays the
+    engine's."""
+    import time
+    B = 700
+    x = np.empty((B, 3, 224, 224), dtype=np.float32)
+    base = R.weights.generate_input(100, seed=91)
+    for i in range(0, B, 100):
+        x[i:i + 100] = base
+    x[511] = finch[0]      # last image of the first sub-batch
+    x[512] = base[7]       # first image of the second
+    x[699] = finch[0]
+    xin = R.FloatTensor.from_numpy(x, R.Device.GPU)
+    out = R.FloatTensor((B, 1000), R.Device.GPU)
+    model50.forward_ptr(xin.data(), B, out.data(), True)
+    model50.ctx.sync()
+    got = out.numpy()
+    assert np.isfinite(got).all()
+    alone = model50.forward(finch, fused=True)
+    assert np.array_equal(got[511:512], alone) and np.array_equal(got[699:700], alone)
+    assert np.array_equal(got[512:513], model50.forward(base[7:8], fused=True))
+    assert np.array_equal(got[600:700][:99], got[0:99])   # the same 100 images again
+    model50.tune(xin.data(), B, out.data(), True)
+    model50.ctx.sync()
+    assert np.array_equal(out.numpy(), got)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        model50.forward_ptr(xin.data(), B, out.data(), True)
+    model50.ctx.sync()
+    rate = 3 * B / (time.perf_counter() - t0)
+    print(f"B=700 as 512 + 188: {rate:.0f} images/s")
+    assert rate > 9000
+    del xin, out
+
+
+def test_sharded_model_equals_whole_batch(state50, model50, finch):
+    """rn_shard_*: one host thread + context + model per listed device, contiguous batch split,
+    logits concatenated on the host (main.cu:228-254 over several devices).  A
+    one-GPU box lists device 0 two and three times: shards must equal the rows of the whole
+    batch bit for bit, in image order, and the class indices those of the host argmax."""
+    B = 7
+    x = R.weights.generate_input(B, seed=55)
+    x[4] = finch[0]
+    whole = model50.forward(x, fused=True)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        g = R.ShardedModel(devices, "resnet50", state=state50)
+        try:
+            logits, top1 = g.forward(x, fused=True)
+            assert np.array_equal(logits, whole), devices
+            assert np.array_equal(top1, R.ops.argmax(whole)), devices
+            assert int(top1[4]) == 112
+            # a batch smaller than the group: the empty shards stay idle
+            l1, t1 = g.forward(x[4:5], fused=True)
+            assert np.array_equal(l1, whole[4:5]) and int(t1[0]) == 112
+            # shard r of the split == rows [lo, hi) of the whole batch, through bench.shard_bounds
+            import bench
+            for r in range(len(devices)):
+                lo, hi = bench.shard_bounds(B, r, len(devices))
+                assert (lo, hi) == R.ShardedModel.bounds(B, r, len(devices))
+                if hi > lo:
+                    assert np.array_equal(model50.forward(x[lo:hi], fused=True), whole[lo:hi])
+        finally:
+            g.close()
+    with pytest.raises(R.RnError):
+        R.ShardedModel([99], "resnet50", state=state50)   # no such device: a status, not a crash
+
+
+def test_plain_c_driver_shards_over_listed_devices(state50, finch, tmp_path):
+    """rn_infer --devices 0,0,0 prints the same 'max index is N' lines, in image order, as the
+    single-device run of the same batch."""
+    wdir = tmp_path / "weights_bin"
+    os.mkdir(wdir)
+    R.weights.save_weights_bin(state50, str(wdir))
+    x = R.weights.generate_input(5, seed=58)
+    x[3] = finch[0]
+    inp = tmp_path / "batch.bin"
+    x.tofile(inp)
+    exe = os.path.join(os.path.dirname(R._lib.LIB_PATH), "rn_infer")
+    base = [exe, "--arch", "50", "--weights", str(wdir), "--input", str(inp), "--batch", "5"]
+    one = subprocess.run(base + ["--device", "0"], capture_output=True, text=True, timeout=300)
+    many = subprocess.run(base + ["--devices", "0,0,0"], capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0 and many.returncode == 0, one.stderr + many.stderr
+    pick = lambda out: [l for l in out.splitlines() if l.startswith("max index is")]
+    assert len(pick(one.stdout)) == 5 and pick(one.stdout) == pick(many.stdout)
+    assert pick(many.stdout)[3] == "max index is 112"
+
+
 def test_host_pipeline_matches_plain_forward_bit_exact(model50, finch):
     """rn_pipeline_* (pinned staging, copy stream, two slots in flight) returns, batch by
     batch and in order, exactly what upload -> rn_model_forward -> download returns."""

@@ -8,6 +8,8 @@ they are compared with rtol 2e-5 / atol 2e-5 * sqrt(K)-scaled magnitude; the dir
 fallback kernel keeps the reference order and is bit-exact with the oracle.
 Batch-norm follows the reference's double-precision expression: <= 1 ulp.
 """
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -228,11 +230,13 @@ def test_batchnorm_matches_double_expression(shape, layout):
 def test_relu_add_any_length_in_place(n):
     a, b = rnd((n,), n), rnd((n,), n + 1)
     a[::7] = -a[::7]
+    want_relu, want_add = O.relu(a), O.add(a, b)   # the oracle's restatement of ops.cu:130-137,153-160
     for inplace in (True, False):
-        assert np.array_equal(ops.relu(a, inplace), np.maximum(a, 0))
-        assert np.array_equal(ops.add(a, b, inplace), a + b)
+        assert np.array_equal(ops.relu(a, inplace), want_relu)
+        assert np.array_equal(ops.add(a, b, inplace), want_add)
     z = np.array([np.nan, -0.0, -1.0, 2.0], dtype=np.float32)
     assert ops.relu(z).tolist() == [0.0, 0.0, 0.0, 2.0]  # fmax(NaN, 0) == 0 (ops.cu:136)
+    assert np.array_equal(ops.relu(z), O.relu(z))
 
 
 @pytest.mark.parametrize("case", [(3, 16, 8), (256, 2048, 1000), (5, 64, 10), (1, 2048, 1000), (2, 7, 3), (70, 96, 130)])
@@ -491,3 +495,71 @@ def test_device_tensor_file_round_trip(tmp_path):
     assert np.array_equal(np.fromfile(out, dtype=np.float32), x.reshape(-1))
     with pytest.raises(RuntimeError):
         t.toDevice(R.Device.GPU)  # same-device copy is unsupported (tensor.cuh:193)
+
+
+def test_packed_weight_cache_of_the_nchw_route():
+    """rn_ctx_set_weight_cache: rn_conv2d_forward (the reference's OIHW / NCHW signature) packs
+    a weight buffer once instead of per call.  Same bits with the cache on or off; an entry dies
+    when the buffer is written through rn_memcpy_h2d or freed."""
+    from resnet_c_amd import _lib as L
+    ctx, lib = R.get_ctx(), L.lib()
+    x = rnd((2, 64, 9, 9), 901)
+    w1, w2 = rnd((96, 64, 3, 3), 902), rnd((96, 64, 3, 3), 903)
+    xd = R.FloatTensor.from_numpy(x, R.Device.GPU)
+    wd = R.FloatTensor.from_numpy(w1, R.Device.GPU)
+    out = R.FloatTensor((2, 96, 9, 9), R.Device.GPU)
+
+    def run():
+        L.check(lib.rn_conv2d_forward(ctx.handle, xd.data(), out.data(), wd.data(), 3, 1, 1, 9, 9, 2, 64, 96, 9, 9),
+                "conv", ctx.handle)
+        ctx.sync()
+        return out.numpy()
+
+    plain1 = run()
+    assert_close(plain1, O.conv2d(x, w1, 1, 1), 64 * 9)
+    ctx.set_weight_cache(True)
+    try:
+        assert np.array_equal(run(), plain1)      # packs and remembers
+        assert np.array_equal(run(), plain1)      # reuses the panel
+        # new values in the same buffer: the entry must die with the write
+        L.check(lib.rn_memcpy_h2d(ctx.handle, wd.data(), w2.ctypes.data, w2.nbytes), "h2d", ctx.handle)
+        got2 = run()
+        assert_close(got2, O.conv2d(x, w2, 1, 1), 64 * 9)
+        assert not np.array_equal(got2, plain1)
+        del wd                                     # rn_free of a cached weight buffer
+        wd = R.FloatTensor.from_numpy(w1, R.Device.GPU)
+        assert np.array_equal(run(), plain1)
+    finally:
+        ctx.set_weight_cache(False)
+    assert np.array_equal(run(), plain1)
+
+
+def test_one_thread_two_contexts_interleaved():
+    """A host thread may own several contexts (on a multi-GPU node: on several devices); every
+    entry point binds its context's device first.  Interleaved calls on two contexts give what
+    each gives alone."""
+    a, b = R.Context(0), R.Context(0)
+    try:
+        from resnet_c_amd import _lib as L
+        lib = L.lib()
+        x = rnd((1 << 16,), 77)
+        bufs = []
+        for c in (a, b):
+            p = ctypes.c_void_p()
+            L.check(lib.rn_malloc(c.handle, ctypes.byref(p), x.nbytes), "malloc", c.handle)
+            L.check(lib.rn_memcpy_h2d(c.handle, p, x.ctypes.data, x.nbytes), "h2d", c.handle)
+            bufs.append(p)
+        for _ in range(3):
+            for c, p in zip((a, b), bufs):
+                L.check(lib.rn_relu_forward(c.handle, p, p, x.size), "relu", c.handle)
+                L.check(lib.rn_add_forward(c.handle, p, p, p, x.size), "add", c.handle)
+        want = O.relu(x)
+        for _ in range(3):
+            want = O.add(O.relu(want), O.relu(want))
+        for c, p in zip((a, b), bufs):
+            got = np.empty_like(x)
+            L.check(lib.rn_memcpy_d2h(c.handle, got.ctypes.data, p, x.nbytes), "d2h", c.handle)
+            assert np.array_equal(got, want)
+            L.check(lib.rn_free(c.handle, p), "free", c.handle)
+    finally:
+        a.close(); b.close()

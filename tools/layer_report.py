@@ -44,10 +44,12 @@ def main():
     tot = sum(r["ms"] for r in acc)
     print(f"{'op':18s} {'layer':24s} {'ms':>8s} {'TF/s':>7s} {'GB/s':>8s} {'ideal_ms':>8s}")
     ideal_tot = 0
+    mfma_peak = 2500e9 if a.dtype == "bf16" else 157.3e9  # flop per ms (MI355X_MICROARCH.md)
     for r in acc:
         tf = r["flops"] / r["ms"] / 1e9 if r["ms"] > 0 else 0
         gb = r["bytes"] / r["ms"] / 1e6 if r["ms"] > 0 else 0
-        ideal = max(r["flops"] / 157.3e9, r["bytes"] / 6.3e9)  # ms at MFMA peak / achievable HBM
+        # ms at the dense MFMA peak of the element type / at the achievable HBM rate
+        ideal = max(r["flops"] / mfma_peak, r["bytes"] / 6.3e9)
         ideal_tot += ideal
         print(f"{r['op']:18s} {r['layer']:24s} {r['ms']:8.3f} {tf:7.1f} {gb:8.0f} {ideal:8.3f}")
     print(f"total {tot:.3f} ms  ({a.batch / tot * 1e3:.0f} img/s by events)  roofline-ideal {ideal_tot:.3f} ms")

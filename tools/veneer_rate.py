@@ -17,8 +17,9 @@ x_host = R.weights.generate_input(a.batch, 0)
 ctx = R.get_ctx()
 x = R.FloatTensor.from_numpy(x_host, R.Device.GPU)
 m = R.createResnet("resnet50", state)
-for sync in (True, False):
+for sync, cache in ((True, False), (False, False), (False, True)):
     ctx.set_sync_each_op(sync)
+    ctx.set_weight_cache(cache)
     for _ in range(2):
         out = R.resnetForward(m, x)
     ctx.sync()
@@ -27,8 +28,10 @@ for sync in (True, False):
         out = R.resnetForward(m, x)
     ctx.sync()
     dt = (time.perf_counter() - t0) / a.steps
-    print(f"NCHW op-by-op graph, sync after each op = {sync}: {dt*1e3:8.2f} ms/forward  {a.batch/dt:8.1f} img/s")
+    print(f"NCHW op-by-op graph, sync after each op = {sync}, packed-weight cache = {cache}: "
+          f"{dt*1e3:8.2f} ms/forward  {a.batch/dt:8.1f} img/s")
 ctx.set_sync_each_op(False)
+ctx.set_weight_cache(False)
 nm = R.NativeModel("resnet50", state=state)
 lg = R.FloatTensor((a.batch, 1000), R.Device.GPU)
 for fused in (False, True):
