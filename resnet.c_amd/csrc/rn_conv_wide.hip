@@ -19,7 +19,8 @@
 //  * rings in LDS: three K tiles of A (two in flight while one is multiplied) and two or three
 //    of B; all 160 KB of the CU for the 256x256 tile.  One barrier per K step, with a counted
 //    s_waitcnt vmcnt(N) in front of it: the wave's own pieces of the tile about to be read
-//    have landed, the younger tile stays in flight across the barrier;
+//    have landed, the younger tile stays in flight across the barrier.  The DMA pieces of a
+//    step are issued between its MFMA groups, not in a block;
 //  * the DMA is issued from inline asm (hipcc would otherwise drain vmcnt(0) in front of every
 //    LDS read); everything else -- fragment reads, MFMAs, the epilogue -- is plain HIP;
 //  * epilogue as in the 4-wave kernel: accumulators -> LDS (fp32, in one or two passes of up to
@@ -27,6 +28,8 @@
 //
 // Roofline: MFMA for K >= ~512 and N >= 128 (the 3x3 convolutions, conv1 of layer3/4, the fused
 // conv3 + downsample pairs); short-K layers stay on the 4-wave kernel (rn_model_tune decides).
+#include <type_traits>
+
 #include "rn_conv_params.h"
 
 using namespace rn_gemm;
@@ -192,13 +195,17 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
     // arithmetic; the per-row offsets change only when the tap does, the segments of one tap go
     // through the scalar offset.  Tiles are issued in increasing kt from 0, so a tap's first
     // segment always passes here before its others.
-    auto issue_a = [&](int kt, int slot) {
+    // prep: the K position of tile kt (tap offsets when a tap begins, descriptor, segment)
+    i32x4 cur_srd = srd_a;
+    int cur_seg = 0, cur_soff_b = 0;
+    unsigned dst_a = 0, dst_b = 0;
+    auto prep_a = [&](int kt, int slot) {
         const unsigned s_kt = (unsigned)__builtin_amdgcn_readfirstlane(kt);
         int s_cs;
-        i32x4 srd = srd_a;
+        cur_srd = srd_a;
         if (DUAL && s_kt >= (unsigned)p.nk1) {
             s_cs = (int)s_kt - p.nk1;
-            srd = srd_a2;
+            cur_srd = srd_a2;
             if (s_cs == 0) {
 #pragma unroll
                 for (int j = 0; j < PA; ++j) a_cur[j] = a_off2[DUAL ? j : 0];
@@ -217,16 +224,36 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
                 }
             }
         }
-        const int seg = s_cs * 128;
-        const unsigned dst = lds_base + (unsigned)(slot * A_SLOT + wave * 1024);
+        cur_seg = s_cs * 128;
+        dst_a = lds_base + (unsigned)(slot * A_SLOT + wave * 1024);
+    };
+    auto prep_b = [&](int kt, int slot) {
+        cur_soff_b = __builtin_amdgcn_readfirstlane(kt) * 128;
+        dst_b = lds_base + (unsigned)(SA * A_SLOT + slot * B_SLOT + wave * 1024);
+    };
+    // A tile past the end of the K loop is still "issued", with out-of-range offsets: zeros land
+    // in a slot nobody reads any more, no global traffic, and the loop body stays one straight
+    // line with one constant vmcnt (a second, DMA-free copy of the step made hipcc keep the
+    // accumulators in two register sets: +128 VGPRs and spills).
+    bool live_a = true, live_b = true;
+    auto dma_a = [&](int j) {
+        dma16(live_a ? a_cur[j] : kOob, cur_srd, cur_seg, dst_a + (unsigned)(j * 8192));
+    };
+    auto dma_b = [&](int j) {
+        dma16(live_b ? b_off[j] : kOob, srd_b, cur_soff_b, dst_b + (unsigned)(j * 8192));
+    };
+    const int nk = p.nk;
+    auto issue_a = [&](int kt, int slot) {
+        live_a = kt < nk;
+        prep_a(live_a ? kt : nk - 1, slot);
 #pragma unroll
-        for (int j = 0; j < PA; ++j) dma16(a_cur[j], srd, seg, dst + (unsigned)(j * 8192));
+        for (int j = 0; j < PA; ++j) dma_a(j);
     };
     auto issue_b = [&](int kt, int slot) {
-        const int soff = __builtin_amdgcn_readfirstlane(kt) * 128;
-        const unsigned dst = lds_base + (unsigned)(SA * A_SLOT + slot * B_SLOT + wave * 1024);
+        live_b = kt < nk;
+        prep_b(kt, slot);
 #pragma unroll
-        for (int j = 0; j < PB; ++j) dma16(b_off[j], srd_b, soff, dst + (unsigned)(j * 8192));
+        for (int j = 0; j < PB; ++j) dma_b(j);
     };
 
     f32x16 acc[MI][NI];
@@ -244,12 +271,17 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) frag_co[ks] = ((2 * ks + lh) ^ sw) * 16;
     const int a_thr = (wm * TM + li) * 128, b_thr = SA * A_SLOT + (wn * TN + li) * 128;
-    // fragment reads and MFMAs of one K tile; hipcc's own interleave of the two (measured: an
-    // explicit one-step-ahead fragment prefetch was 8-15 % slower)
-    auto compute = [&](int sa, int sb) {
+    // One K step: fragment reads and MFMAs of tile (sa, sb), and between the MFMA groups of its
+    // four k-steps the step's DMA pieces -- piece(i) issues the i-th.  Issued as one block after
+    // the barrier, the pieces kept the matrix pipe idle (a wave issues in order, and its SIMD
+    // partner does the same thing at the same time): spread out, 6-34 % faster per layer.
+    // The fragment reads are left to hipcc's own interleave: an explicit one-k-step-ahead
+    // prefetch (second fragment set, sched_group_barrier slots) measured 2-9 % slower, and
+    // giving the two waves of a SIMD different k-steps to issue their pieces in 2-12 % slower.
+    auto compute = [&](int sa, int sb, auto npieces, auto piece) {
+        constexpr int NP = decltype(npieces)::value;
         const char *const abase = lds + a_thr + sa * A_SLOT;
         const char *const bbase = lds + b_thr + sb * B_SLOT;
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             i32x4 a[MI], b[NI];
@@ -266,43 +298,51 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni],
                         0, 0, 0);
+#pragma unroll
+            for (int i = ks * NP / 4; i < (ks + 1) * NP / 4; ++i) piece(i);
         }
-        __builtin_amdgcn_s_setprio(0);
     };
+    using AllPieces = std::integral_constant<int, PA + PB>;
 
     // ---- K loop ----------------------------------------------------------------------------
     // issue order is what the counted waits rely on:
     //   SB == 3:  prologue A0 B0 A1 B1; step t issues A(t+2) B(t+2);  wait leaves A(t+1) B(t+1)
     //   SB == 2:  prologue A0 B0 A1;    step t issues B(t+1) A(t+2);  wait leaves A(t+1)
-    const int nk = p.nk;
     issue_a(0, 0);
     issue_b(0, 0);
-    if (nk > 1) {
-        issue_a(1, 1);
-        if constexpr (SB == 3) issue_b(1, 1);
-    }
+    issue_a(1, 1);
+    if constexpr (SB == 3) issue_b(1, 1);
     int sa = 0, sb = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk)
-            wait_and_barrier<SB == 3 ? PA + PB : PA>();
-        else
-            wait_and_barrier<0>();
+        wait_and_barrier<SB == 3 ? PA + PB : PA>();
         if (kt == 0) {
             stamp(p.stamps, 1);
             stamp_cycles(p.stamps, 8);
         }
         // every wave is past its reads of tile kt-1: its slots take the tiles after next
-        if constexpr (SB == 3) {
-            if (kt + 2 < nk) {
-                const int s2 = sa == 0 ? 2 : sa - 1;
-                issue_a(kt + 2, s2);
-                issue_b(kt + 2, sb == 0 ? 2 : sb - 1);
-            }
-        } else {
-            if (kt + 1 < nk) issue_b(kt + 1, sb ^ 1);
-            if (kt + 2 < nk) issue_a(kt + 2, sa == 0 ? 2 : sa - 1);
+        const int sa2 = sa == 0 ? 2 : sa - 1;
+        if constexpr (SB == 3) {  // pieces in issue order: A(kt+2), then B(kt+2)
+            live_a = live_b = kt + 2 < nk;
+            prep_a(live_a ? kt + 2 : nk - 1, sa2);
+            prep_b(kt + 2, sb == 0 ? 2 : sb - 1);
+            compute(sa, sb, AllPieces{}, [&](int i) {
+                if (i < PA)
+                    dma_a(i);
+                else
+                    dma_b(i - PA);
+            });
+        } else {  // pieces in issue order: B(kt+1), then A(kt+2)
+            live_b = kt + 1 < nk;
+            live_a = kt + 2 < nk;
+            prep_b(kt + 1, sb ^ 1);
+            prep_a(live_a ? kt + 2 : nk - 1, sa2);
+            compute(sa, sb, AllPieces{}, [&](int i) {
+                if (i < PB)
+                    dma_b(i);
+                else
+                    dma_a(i - PB);
+            });
         }
-        compute(sa, sb);
         sa = sa == SA - 1 ? 0 : sa + 1;
         sb = sb == SB - 1 ? 0 : sb + 1;
     }
