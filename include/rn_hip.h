@@ -271,6 +271,12 @@ RN_API int rn_model_set_pair_fusion(rn_model *m, int on);
 /* fp32 models: stem through rn_conv2d_nhwc_exact_forward (K = 160; default) or through the
  * 4-channel / 8-slot form of rn_conv2d_nhwc_forward (K = 224).  Invalidates the tuned tiles. */
 RN_API int rn_model_set_stem_exact(rn_model *m, int on);
+/* streams = 1, 2 (default) or 4: a (sub-)batch runs as that many contiguous parts (of at least
+ * 64 images each) on streams of their own -- the launches of one part fill the tails of the
+ * others'; every image's logits are independent of what else is in its launch, so no bit
+ * changes.  Profiled and tuning forwards always use one stream.  Changing it invalidates the
+ * tuned tiles. */
+RN_API int rn_model_set_streams(rn_model *m, int streams);
 RN_API int rn_model_set_profiling(rn_model *m, int on);
 /* after a profiled forward + rn_sync: number of ops, then one record per op */
 RN_API uint64_t rn_model_profile_count(const rn_model *m);

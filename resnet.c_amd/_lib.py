@@ -100,6 +100,7 @@ SIGNATURES = {
                                        + [POINTER(ConvSecond), POINTER(Epilogue)]),
     "rn_model_set_pair_fusion": (c_int, [c_void_p, c_int]),
     "rn_model_set_stem_exact": (c_int, [c_void_p, c_int]),
+    "rn_model_set_streams": (c_int, [c_void_p, c_int]),
     "rn_maxpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),
     "rn_avgpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),
     "rn_model_create": (c_int, [c_void_p, POINTER(c_void_p), c_int]),

@@ -220,6 +220,15 @@ int rn_ctx_set_split_k(rn_ctx *ctx, int max_splits)
     return RN_OK;
 }
 
+// library-internal: everything queued on ctx's stream after this call waits for the event
+int rn_ctx_wait_event(rn_ctx *ctx, rn_event *ev)
+{
+    if (!ctx || !ev) return RN_ERR_INVALID;
+    RN_TRY(rn_bind_device(ctx));
+    RN_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev->ev, 0));
+    return RN_OK;
+}
+
 uint64_t rn_ctx_launch_count(const rn_ctx *ctx) { return ctx ? ctx->launches : 0; }
 
 int rn_ctx_set_weight_cache(rn_ctx *ctx, int on)

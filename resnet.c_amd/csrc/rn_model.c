@@ -30,6 +30,8 @@
 #define RN_MAX_KEY 96
 #define RN_CLASSES 1000
 
+#define RN_MAX_STREAMS 4
+
 typedef struct {
     char key[RN_MAX_KEY];
     uint64_t numel;
@@ -97,6 +99,17 @@ struct rn_model {
     uint64_t batch_cap;
     float *x4, *p0, *p1, *dsb, *t1, *t2, *pooled;
     uint64_t act_bytes;
+    /* Two halves of a batch on two streams: the launches of one half fill the tails (last
+     * round of tiles, prologues, epilogues) of the other's.  Every image's logits are
+     * independent of what else is in its launch, so the split changes no bit.  The second
+     * stream belongs to a second context on the same device (own scratch). */
+    int streams;            /* parts a sub-batch is split into (each >= RN_STREAM_MIN_PART images) */
+    rn_ctx *ctxn[RN_MAX_STREAMS - 1];     /* contexts of parts 1.. (part 0 runs on ctx) */
+    rn_event *ev_fork, *ev_join[RN_MAX_STREAMS - 1];
+    int single_stream_only; /* tuning pass: its recorded calls are one half */
+    /* what the ops of the sub-batch being queued run on: context, and views into the arenas */
+    rn_ctx *run;
+    struct { float *x4, *p0, *p1, *dsb, *t1, *t2, *pooled; } v;
     /* tile tuning: calls of the last forward, and the batch size the tiles were tuned for */
     rn_conv_call *calls;
     int n_calls, recording;
@@ -161,6 +174,7 @@ int rn_model_create(rn_ctx *ctx, rn_model **out, int arch)
     else return RN_ERR_UNSUPPORTED;
     m = (rn_model *)calloc(1, sizeof(rn_model));
     if (m) m->pair_fusion = m->stem_exact = 1;
+    if (m) m->streams = 2;
     if (!m) return RN_ERR_NOMEM;
     m->ctx = ctx;
     m->arch = arch;
@@ -264,6 +278,16 @@ int rn_model_destroy(rn_model *m)
     rn_free(m->ctx, m->stem_packed_exact);
     free_acts(m);
     free_prof(m);
+    {
+        int k;
+        rn_event_destroy(m->ev_fork);
+        for (k = 0; k < RN_MAX_STREAMS - 1; ++k) {
+            if (!m->ctxn[k]) continue;
+            rn_sync(m->ctxn[k]);
+            rn_event_destroy(m->ev_join[k]);
+            rn_ctx_destroy(m->ctxn[k]);
+        }
+    }
     free(m->params);
     free(m->convs);
     free(m->blocks);
@@ -475,6 +499,14 @@ int rn_model_set_pair_fusion(rn_model *m, int on)
     return RN_OK;
 }
 
+int rn_model_set_streams(rn_model *m, int streams)
+{
+    if (!m || (streams != 1 && streams != 2 && streams != 4)) return RN_ERR_INVALID;
+    m->streams = streams;
+    m->tuned_B = 0; /* the launches change size */
+    return RN_OK;
+}
+
 int rn_model_set_stem_exact(rn_model *m, int on)
 {
     if (!m) return RN_ERR_INVALID;
@@ -499,8 +531,8 @@ static int prof_begin(rn_model *m, const char *op, const char *layer, double flo
         for (i = m->cap_prof; i < ncap; ++i) {
             int st;
             memset(&np[i], 0, sizeof(rn_prof));
-            st = rn_event_create(m->ctx, &np[i].start);
-            if (st == RN_OK) st = rn_event_create(m->ctx, &np[i].stop);
+            st = rn_event_create(m->run, &np[i].start);
+            if (st == RN_OK) st = rn_event_create(m->run, &np[i].stop);
             if (st != RN_OK) {
                 m->cap_prof = i;
                 return st;
@@ -514,13 +546,13 @@ static int prof_begin(rn_model *m, const char *op, const char *layer, double flo
     r->flops = flops;
     r->bytes = bytes;
     r->ms = -1.f;
-    return rn_event_record(m->ctx, r->start);
+    return rn_event_record(m->run, r->start);
 }
 
 static int prof_end(rn_model *m)
 {
     if (!m->profiling) return RN_OK;
-    return rn_event_record(m->ctx, m->prof[m->n_prof++].stop);
+    return rn_event_record(m->run, m->prof[m->n_prof++].stop);
 }
 
 int rn_model_set_profiling(rn_model *m, int on)
@@ -589,15 +621,15 @@ static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint6
     }
     TRY(prof_begin(m, ep ? "conv2d+epilogue" : "conv2d", cv->name, 2.0 * M * (double)cv->cout * K,
                    bytes));
-    rn_ctx_set_conv_tile(m->ctx, (m->tuned_B == B && m->tuned_mode == m->cur_mode) ? cv->tile : 0);
+    rn_ctx_set_conv_tile(m->run, (m->tuned_B == B && m->tuned_mode == m->cur_mode) ? cv->tile : 0);
     {
         const int st =
-            exact ? rn_conv2d_nhwc_exact_forward(m->ctx, (const float *)x, (float *)y,
+            exact ? rn_conv2d_nhwc_exact_forward(m->run, (const float *)x, (float *)y,
                                                  m->stem_packed_exact, cv->k, cv->stride, ho, wo, B,
                                                  cv->cin, cv->cout, H, W, ep)
-                  : rn_conv2d_nhwc_forward_dt(m->ctx, m->dtype, m->dtype, x, y, cv->packed, cv->k,
+                  : rn_conv2d_nhwc_forward_dt(m->run, m->dtype, m->dtype, x, y, cv->packed, cv->k,
                                               cv->stride, pad, ho, wo, B, cv->cin, cv->cout, H, W, ep);
-        rn_ctx_set_conv_tile(m->ctx, 0);
+        rn_ctx_set_conv_tile(m->run, 0);
         if (st != RN_OK) return st;
     }
     return prof_end(m);
@@ -631,11 +663,11 @@ static int op_pair(rn_model *m, rn_block *b, const void *t, const void *x, void 
     }
     snprintf(name, sizeof(name), "%.*s+downsample", (int)(RN_MAX_KEY - 12), c3->name);
     TRY(prof_begin(m, "conv2d+epilogue", name, 2.0 * M * (double)c3->cout * K, bytes));
-    rn_ctx_set_conv_tile(m->ctx, (m->tuned_B == B && m->tuned_mode == m->cur_mode) ? b->pair_tile : 0);
-    st = rn_conv2d_nhwc_pair_forward_dt(m->ctx, m->dtype, m->dtype, t, y, b->pair_packed, c3->k,
+    rn_ctx_set_conv_tile(m->run, (m->tuned_B == B && m->tuned_mode == m->cur_mode) ? b->pair_tile : 0);
+    st = rn_conv2d_nhwc_pair_forward_dt(m->run, m->dtype, m->dtype, t, y, b->pair_packed, c3->k,
                                         c3->stride, c3->pad, H, W, B, c3->cin, c3->cout, H, W,
                                         &second, &ep);
-    rn_ctx_set_conv_tile(m->ctx, 0);
+    rn_ctx_set_conv_tile(m->run, 0);
     if (st != RN_OK) return st;
     return prof_end(m);
 }
@@ -644,7 +676,7 @@ static int op_bn(rn_model *m, const rn_conv *cv, float *y, uint64_t B, uint64_t 
 {
     const double n = (double)(B * cv->cout * HW);
     TRY(prof_begin(m, "batchnorm2d", cv->name, 0.0, 8.0 * n + 16.0 * (double)cv->cout));
-    TRY(rn_batchnorm2d_forward(m->ctx, y, y, m->params[cv->bn_w].dev, m->params[cv->bn_b].dev,
+    TRY(rn_batchnorm2d_forward(m->run, y, y, m->params[cv->bn_w].dev, m->params[cv->bn_b].dev,
                                m->params[cv->bn_m].dev, m->params[cv->bn_v].dev, B, cv->cout, HW));
     return prof_end(m);
 }
@@ -652,14 +684,14 @@ static int op_bn(rn_model *m, const rn_conv *cv, float *y, uint64_t B, uint64_t 
 static int op_relu(rn_model *m, const char *layer, float *y, uint64_t n)
 {
     TRY(prof_begin(m, "relu", layer, 0.0, 8.0 * (double)n));
-    TRY(rn_relu_forward(m->ctx, y, y, n));
+    TRY(rn_relu_forward(m->run, y, y, n));
     return prof_end(m);
 }
 
 static int op_add(rn_model *m, const char *layer, float *y, const float *shortcut, uint64_t n)
 {
     TRY(prof_begin(m, "add", layer, 0.0, 12.0 * (double)n));
-    TRY(rn_add_forward(m->ctx, y, shortcut, y, n)); /* out aliases inp1: main.cu:162 */
+    TRY(rn_add_forward(m->run, y, shortcut, y, n)); /* out aliases inp1: main.cu:162 */
     return prof_end(m);
 }
 
@@ -678,34 +710,34 @@ static int block_forward(rn_model *m, rn_block *b, const float *x, float *y, uin
         if (b->ds >= 0 && !pair) {
             const rn_conv *cd = &m->convs[b->ds];
             ep.scale = cd->scale; ep.shift = cd->shift; ep.residual = NULL; ep.relu = 0;
-            TRY(op_conv(m, cd, x, m->dsb, B, h, w, &ep, -1));
-            shortcut = m->dsb;
+            TRY(op_conv(m, cd, x, m->v.dsb, B, h, w, &ep, -1));
+            shortcut = m->v.dsb;
         }
         ep.scale = c1->scale; ep.shift = c1->shift; ep.residual = NULL; ep.relu = 1;
-        TRY(op_conv(m, c1, x, m->t1, B, h, w, &ep, -1));
+        TRY(op_conv(m, c1, x, m->v.t1, B, h, w, &ep, -1));
         ep.scale = c2->scale; ep.shift = c2->shift;
-        TRY(op_conv(m, c2, m->t1, m->t2, B, h, w, &ep, -1));
+        TRY(op_conv(m, c2, m->v.t1, m->v.t2, B, h, w, &ep, -1));
         if (pair) {
             /* the downsample tensor is never materialised: its K rows ride in conv3's loop */
-            TRY(op_pair(m, b, m->t2, x, y, B, ho, wo, h, w));
+            TRY(op_pair(m, b, m->v.t2, x, y, B, ho, wo, h, w));
         } else {
             ep.scale = c3->scale; ep.shift = c3->shift; ep.residual = shortcut;
-            TRY(op_conv(m, c3, m->t2, y, B, ho, wo, &ep, -1));
+            TRY(op_conv(m, c3, m->v.t2, y, B, ho, wo, &ep, -1));
         }
     } else {
         if (b->ds >= 0) {
             const rn_conv *cd = &m->convs[b->ds];
-            TRY(op_conv(m, cd, x, m->dsb, B, h, w, NULL, -1));
-            TRY(op_bn(m, cd, m->dsb, B, ho * wo));
-            shortcut = m->dsb;
+            TRY(op_conv(m, cd, x, m->v.dsb, B, h, w, NULL, -1));
+            TRY(op_bn(m, cd, m->v.dsb, B, ho * wo));
+            shortcut = m->v.dsb;
         }
-        TRY(op_conv(m, c1, x, m->t1, B, h, w, NULL, -1));
-        TRY(op_bn(m, c1, m->t1, B, h * w));
-        TRY(op_relu(m, c1->name, m->t1, B * h * w * c1->cout));
-        TRY(op_conv(m, c2, m->t1, m->t2, B, h, w, NULL, -1));
-        TRY(op_bn(m, c2, m->t2, B, ho * wo));
-        TRY(op_relu(m, c2->name, m->t2, B * ho * wo * c2->cout));
-        TRY(op_conv(m, c3, m->t2, y, B, ho, wo, NULL, -1));
+        TRY(op_conv(m, c1, x, m->v.t1, B, h, w, NULL, -1));
+        TRY(op_bn(m, c1, m->v.t1, B, h * w));
+        TRY(op_relu(m, c1->name, m->v.t1, B * h * w * c1->cout));
+        TRY(op_conv(m, c2, m->v.t1, m->v.t2, B, h, w, NULL, -1));
+        TRY(op_bn(m, c2, m->v.t2, B, ho * wo));
+        TRY(op_relu(m, c2->name, m->v.t2, B * ho * wo * c2->cout));
+        TRY(op_conv(m, c3, m->v.t2, y, B, ho, wo, NULL, -1));
         TRY(op_bn(m, c3, y, B, ho * wo));
         TRY(op_add(m, b->name, y, shortcut, B * ho * wo * c3->cout));
         TRY(op_relu(m, b->name, y, B * ho * wo * c3->cout));
@@ -715,18 +747,30 @@ static int block_forward(rn_model *m, rn_block *b, const float *x, float *y, uin
     return RN_OK;
 }
 
-/* One sub-batch: every tensor of it stays below the kernels' 2^29-element range. */
-static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
+int rn_ctx_wait_event(rn_ctx *ctx, rn_event *ev); /* rn_ctx.hip: the stream waits, not the host */
+
+/* B images whose activations live at image offset img_off of the arenas, queued on `run`. */
+static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *input_nchw,
+                       uint64_t B, float *logits, int mode)
 {
     const rn_conv *stem;
     uint64_t H = 224, W = 224, ho, wo, ph, pw;
     float *x, *y, *tmp;
     int bi, saved_layout, st;
-    TRY(ensure_acts(m, B));
-    m->n_prof = 0;
+    {
+        const uint64_t es = elem_size(m);
+        m->run = run;
+        m->v.x4 = (float *)((char *)m->x4 + img_off * X4_PER_IMG * es);
+        m->v.p0 = (float *)((char *)m->p0 + img_off * P_PER_IMG * es);
+        m->v.p1 = (float *)((char *)m->p1 + img_off * P_PER_IMG * es);
+        m->v.dsb = (float *)((char *)m->dsb + img_off * P_PER_IMG * es);
+        m->v.t1 = (float *)((char *)m->t1 + img_off * T_PER_IMG * es);
+        m->v.t2 = (float *)((char *)m->t2 + img_off * T_PER_IMG * es);
+        m->v.pooled = (float *)((char *)m->pooled + img_off * 2048 * es);
+    }
     m->cur_mode = mode;
-    saved_layout = rn_ctx_get_layout(m->ctx);
-    rn_ctx_set_layout(m->ctx, RN_LAYOUT_NHWC);
+    saved_layout = rn_ctx_get_layout(m->run);
+    rn_ctx_set_layout(m->run, RN_LAYOUT_NHWC);
     st = RN_OK;
     do {
 #define STEP(expr) if ((st = (expr)) != RN_OK) break
@@ -738,14 +782,14 @@ static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float
             const uint64_t border = stem->pad;
             STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0,
                             (double)B * (4.0 * 3 * 224 * 224 + es * 230 * 230 * 4)));
-            STEP(rn_nchw_to_nhwc_pad_dt(m->ctx, m->dtype, input_nchw, m->x4, B, 3, H, W, 4, border));
+            STEP(rn_nchw_to_nhwc_pad_dt(m->run, m->dtype, input_nchw, m->v.x4, B, 3, H, W, 4, border));
             STEP(prof_end(m));
             ho = rn_conv_output_size(H + 2 * border, stem->k, stem->stride, 0);
             wo = rn_conv_output_size(W + 2 * border, stem->k, stem->stride, 0);
             {
                 rn_epilogue ep;
                 ep.scale = stem->scale; ep.shift = stem->shift; ep.residual = NULL; ep.relu = 1;
-                STEP(op_conv(m, stem, m->x4, m->p1, B, H + 2 * border, W + 2 * border, &ep, 0));
+                STEP(op_conv(m, stem, m->v.x4, m->v.p1, B, H + 2 * border, W + 2 * border, &ep, 0));
             }
         } else {
             /* exact-K form: [B,230,230,3] with a physical border; else [B,224,224,4] */
@@ -755,11 +799,11 @@ static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float
             if (m->stem_exact) {
                 STEP(prof_begin(m, "nchw_to_nhwc3", "input", 0.0,
                                 4.0 * (double)B * (3.0 * 224 * 224 + 3.0 * 230 * 230)));
-                STEP(rn_nchw_to_nhwc_pad_dt(m->ctx, RN_DTYPE_F32, input_nchw, m->x4, B, 3, H, W, 3,
+                STEP(rn_nchw_to_nhwc_pad_dt(m->run, RN_DTYPE_F32, input_nchw, m->v.x4, B, 3, H, W, 3,
                                             border));
             } else {
                 STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0, 4.0 * (double)(B * 224 * 224 * 7)));
-                STEP(rn_nchw_to_nhwc_pad(m->ctx, input_nchw, m->x4, B, 3, H, W, 4));
+                STEP(rn_nchw_to_nhwc_pad(m->run, input_nchw, m->v.x4, B, 3, H, W, 4));
             }
             STEP(prof_end(m));
             ho = rn_conv_output_size(H, stem->k, stem->stride, stem->pad);
@@ -767,11 +811,11 @@ static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float
             if (mode == RN_FWD_FUSED) {
                 rn_epilogue ep;
                 ep.scale = stem->scale; ep.shift = stem->shift; ep.residual = NULL; ep.relu = 1;
-                STEP(op_conv(m, stem, m->x4, m->p1, B, sh, sw, &ep, form));
+                STEP(op_conv(m, stem, m->v.x4, m->v.p1, B, sh, sw, &ep, form));
             } else {
-                STEP(op_conv(m, stem, m->x4, m->p1, B, sh, sw, NULL, form));
-                STEP(op_bn(m, stem, m->p1, B, ho * wo));
-                STEP(op_relu(m, "conv1", m->p1, B * ho * wo * 64));
+                STEP(op_conv(m, stem, m->v.x4, m->v.p1, B, sh, sw, NULL, form));
+                STEP(op_bn(m, stem, m->v.p1, B, ho * wo));
+                STEP(op_relu(m, "conv1", m->v.p1, B * ho * wo * 64));
             }
         }
         /* maxpool 3x3 s2 p1 (main.cu:114,192) */
@@ -779,13 +823,13 @@ static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float
         pw = rn_conv_output_size(wo, 3, 2, 1);
         STEP(prof_begin(m, "maxpool2d", "maxpool", 0.0,
                         es * (double)(B * 64 * (ho * wo + ph * pw))));
-        STEP(rn_maxpool2d_nhwc_forward_dt(m->ctx, m->dtype, m->p1, m->p0, 3, 2, 1, ph, pw, B, 64, ho,
+        STEP(rn_maxpool2d_nhwc_forward_dt(m->run, m->dtype, m->v.p1, m->v.p0, 3, 2, 1, ph, pw, B, 64, ho,
                                           wo));
         STEP(prof_end(m));
         H = ph;
         W = pw;
-        x = m->p0;
-        y = m->p1;
+        x = m->v.p0;
+        y = m->v.p1;
         for (bi = 0; bi < m->n_blocks; ++bi) {
             STEP(block_forward(m, &m->blocks[bi], x, y, B, &H, &W, mode));
             tmp = x; x = y; y = tmp;
@@ -793,7 +837,7 @@ static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float
         if (st != RN_OK) break;
         /* global 7x7 average (main.cu:120,213) then fc (main.cu:122,224) */
         STEP(prof_begin(m, "avgpool2d", "avgpool", 0.0, es * (double)(B * 2048 * (H * W + 1))));
-        STEP(rn_avgpool2d_nhwc_forward_dt(m->ctx, m->dtype, x, m->pooled, 7, 1, 0,
+        STEP(rn_avgpool2d_nhwc_forward_dt(m->run, m->dtype, x, m->v.pooled, 7, 1, 0,
                                           rn_conv_output_size(H, 7, 1, 0),
                                           rn_conv_output_size(W, 7, 1, 0), B, 2048, H, W));
         STEP(prof_end(m));
@@ -803,18 +847,53 @@ static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float
         if (bf16) {
             rn_epilogue ep;
             ep.scale = NULL; ep.shift = m->params[m->fc_b].dev; ep.residual = NULL; ep.relu = 0;
-            STEP(rn_conv2d_nhwc_forward_dt(m->ctx, m->dtype, RN_DTYPE_F32, m->pooled, logits,
+            STEP(rn_conv2d_nhwc_forward_dt(m->run, m->dtype, RN_DTYPE_F32, m->v.pooled, logits,
                                            m->fc_packed, 1, 1, 0, 1, 1, B, 2048, RN_CLASSES, 1, 1,
                                            &ep));
         } else {
-            STEP(rn_linear_forward(m->ctx, m->pooled, logits, m->params[m->fc_w].dev,
+            STEP(rn_linear_forward(m->run, m->v.pooled, logits, m->params[m->fc_w].dev,
                                    m->params[m->fc_b].dev, B, 2048, RN_CLASSES));
         }
         STEP(prof_end(m));
 #undef STEP
     } while (0);
-    rn_ctx_set_layout(m->ctx, saved_layout);
+    rn_ctx_set_layout(m->run, saved_layout);
     return st;
+}
+
+#define RN_STREAM_MIN_PART 64
+
+/* One sub-batch: every tensor of it stays below the kernels' 2^29-element range.  Large enough,
+ * it runs as `streams` contiguous parts on as many streams (see rn_model.streams). */
+static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
+{
+    uint64_t lo = 0;
+    int parts = m->streams, i;
+    TRY(ensure_acts(m, B));
+    m->n_prof = 0;
+    while (parts > 1 && B / (uint64_t)parts < RN_STREAM_MIN_PART) parts /= 2;
+    if (parts < 2 || m->profiling || m->single_stream_only || m->recording)
+        return forward_sub(m, m->ctx, 0, input_nchw, B, logits, mode);
+    if (!m->ev_fork) TRY(rn_event_create(m->ctx, &m->ev_fork));
+    for (i = 0; i < parts - 1; ++i) {
+        if (m->ctxn[i]) continue;
+        TRY(rn_ctx_create(&m->ctxn[i], rn_ctx_device(m->ctx), NULL));
+        TRY(rn_event_create(m->ctxn[i], &m->ev_join[i]));
+    }
+    /* fork: whatever the caller queued before this forward (the input upload) is done before
+     * the other streams start; join: the first stream carries on after every part */
+    TRY(rn_event_record(m->ctx, m->ev_fork));
+    for (i = 0; i < parts; ++i) {
+        const uint64_t hi = B * (uint64_t)(i + 1) / (uint64_t)parts;
+        rn_ctx *run = i == 0 ? m->ctx : m->ctxn[i - 1];
+        if (i > 0) TRY(rn_ctx_wait_event(run, m->ev_fork));
+        TRY(forward_sub(m, run, lo, input_nchw + lo * 3 * 224 * 224, hi - lo, logits + lo * RN_CLASSES,
+                        mode));
+        if (i > 0) TRY(rn_event_record(run, m->ev_join[i - 1]));
+        lo = hi;
+    }
+    for (i = 0; i < parts - 1; ++i) TRY(rn_ctx_wait_event(m->ctx, m->ev_join[i]));
+    return RN_OK;
 }
 
 /* The reference has no batch limit other than memory (main.cu:168-226).  Here the contraction
@@ -848,12 +927,19 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
     const uint64_t B_all = B;
     if (!m) return RN_ERR_INVALID;
     if (B > RN_MAX_SUB_BATCH) B = RN_MAX_SUB_BATCH; /* the launches of a larger batch are sub-batches */
+    {   /* ... and those run as `streams` parts */
+        int parts = m->streams;
+        while (parts > 1 && B / (uint64_t)parts < RN_STREAM_MIN_PART) parts /= 2;
+        if (parts > 1) B /= (uint64_t)parts;
+    }
+    m->single_stream_only = 1;
     /* one recorded forward with the per-launch choice: fills the buffers with real data */
     m->tuned_B = 0;
     m->n_calls = 0;
     m->recording = 1;
     st = rn_model_forward(m, input_nchw, B, logits, mode);
     m->recording = 0;
+    m->single_stream_only = 0;
     if (st != RN_OK) return st;
     st = rn_event_create(m->ctx, &e0);
     if (st == RN_OK) st = rn_event_create(m->ctx, &e1);

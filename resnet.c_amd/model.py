@@ -266,6 +266,10 @@ class NativeModel:
         on) or as two launches with the downsample tensor as the residual."""
         L.check(L.lib().rn_model_set_pair_fusion(self.handle, int(on)), "rn_model_set_pair_fusion")
 
+    def set_streams(self, streams: int) -> None:
+        """2 (default): batches of >= 128 images run as two halves on two streams; 1: one stream."""
+        L.check(L.lib().rn_model_set_streams(self.handle, int(streams)), "rn_model_set_streams")
+
     def set_stem_exact(self, on: bool) -> None:
         """fp32: stem in the exact-K form (K = 160, default) or the 4-channel slot form (224)."""
         L.check(L.lib().rn_model_set_stem_exact(self.handle, int(on)), "rn_model_set_stem_exact")

@@ -14,6 +14,8 @@ import csv, glob, json, os, sys
 def family(name):
     if "conv_gemm_kernel" in name:
         return "conv_gemm_kernel"
+    if "conv_wide_kernel" in name:
+        return "conv_wide_kernel"
     n = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return n.split("(")[0].split("<")[0]
 
@@ -35,6 +37,13 @@ def main():
     out = {"forwards": F, "span_ms_per_forward": span_ns / F / 1e6,
            "kernels": {k: {"launches_per_forward": v[0] / F, "avg_us": v[1] / v[0] / 1e3,
                            "ms_per_forward": v[1] / F / 1e6} for k, v in sorted(fam.items())}}
+    # the contraction family as bench.py's `roofline` counts it: the implicit-GEMM launches plus
+    # the launches that add the K-chunk pieces of cut tail tiles
+    con = [v for k, v in fam.items() if k in ("conv_gemm_kernel", "conv_wide_kernel", "splitk_finish_kernel")]
+    if con:
+        n, ns = sum(v[0] for v in con), sum(v[1] for v in con)
+        out["contraction_family"] = {"launches_per_forward": n / F, "avg_us": ns / n / 1e3,
+                                     "ms_per_forward": ns / F / 1e6}
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 3:
         json.dump(out, open(sys.argv[3], "w"), indent=1)

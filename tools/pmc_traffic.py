@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""HBM traffic of the contraction kernel from two rocprofv3 --pmc passes (FETCH_SIZE and
-WRITE_SIZE cannot share a pass on gfx950: TCC slot limit).  Uses the 50 conv_gemm dispatches
-of the LAST forward of each run; FETCH_SIZE is doubled (gfx950 reports half the bytes of a
-wide coalesced read stream, MI355X_MICROARCH.md section HBM); both counters are in KiB.
+"""HBM traffic of the contraction kernels from two rocprofv3 --pmc passes (FETCH_SIZE and
+WRITE_SIZE cannot share a pass on gfx950: TCC slot limit).  Uses the contraction dispatches
+(conv_gemm_kernel, conv_wide_kernel, splitk_finish_kernel) of the LAST forward of each run;
+FETCH_SIZE is doubled (gfx950 reports half the bytes of a wide coalesced read stream,
+MI355X_MICROARCH.md section HBM); both counters are in KiB.
 
-    python tools/pmc_traffic.py gpurun_out/pmc_r1_FETCH_SIZE gpurun_out/pmc_r1_WRITE_SIZE out.json
+    python tools/pmc_traffic.py <FETCH dir> <WRITE dir> out.json [launches per forward] [algorithmic bytes] [note]
 """
 import csv
 import glob
@@ -13,23 +14,29 @@ import os
 import sys
 
 
-def last_forward(d, counter, n=50):
+FAMILY = ("conv_gemm_kernel", "conv_wide_kernel", "splitk_finish_kernel")
+
+
+def last_forward(d, counter, n):
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if r["Counter_Name"] == counter and "conv_gemm_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+    vals = [float(r["Counter_Value"]) for r in rows if any(k in r["Kernel_Name"] for k in FAMILY)]
     return vals[-n:]
 
 
 def main():
-    fe = last_forward(sys.argv[1], "FETCH_SIZE")
-    wr = last_forward(sys.argv[2], "WRITE_SIZE")
+    n = int(sys.argv[4]) if len(sys.argv) > 4 else 72
+    fe = last_forward(sys.argv[1], "FETCH_SIZE", n)
+    wr = last_forward(sys.argv[2], "WRITE_SIZE", n)
     fetch = sum(fe) * 1024 * 2
     write = sum(wr) * 1024
-    out = {"kernel": "conv_gemm_kernel", "launches": len(fe),
+    out = {"kernel": " + ".join(FAMILY), "launches": len(fe),
            "fetch_bytes_per_forward_x2_corrected": fetch, "write_bytes_per_forward": write,
            "traffic_bytes_per_launch": (fetch + write) / len(fe),
-           "algorithmic_bytes_per_forward": 24.97e9,
-           "note": "ResNet-50 fp32 B=256 fused mode; separate --pmc passes; FETCH_SIZE x2"}
+           "algorithmic_bytes_per_forward": float(sys.argv[5]) if len(sys.argv) > 5 else 24.97e9,
+           "note": sys.argv[6] if len(sys.argv) > 6 else
+           "ResNet-50 fp32 B=256 fused mode; separate --pmc passes; FETCH_SIZE x2"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     print(out)
 
