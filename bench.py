@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--no-tune", action="store_true", help="skip the per-layer tile tuning pass")
     ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 4],
                     help="parts of a batch that run on streams of their own (they fill each other's kernel tails)")
+    ap.add_argument("--front-parts", type=int, default=1,
+                    help="stem + max-pool + first stage in this many slices per batch part (Infinity-Cache reuse)")
     ap.add_argument("--profile-forwards", type=int, default=3)
     args = ap.parse_args()
 
@@ -247,6 +249,7 @@ def main():
     state = R.weights.generate_state(args.arch, seed=0)
     model = R.NativeModel(args.arch, state=state, ctx=ctx, dtype=args.dtype)
     model.set_streams(args.streams)
+    model.set_front_parts(args.front_parts)
     lo, hi = shard_bounds(world * B, rank, world)
     # this rank's shard of the global batch: image i depends on (seed, i) only
     per = 3 * 224 * 224
@@ -342,7 +345,7 @@ def main():
                                   else "(BASELINE.json configs[4])"),
                    "global_batch": world * B, "batch_per_gpu": B,
                    "mode": "fused conv+bn+relu(+add) epilogues" if fused else "one kernel per reference op",
-                   "streams_per_gpu": args.streams,
+                   "streams_per_gpu": args.streams, "front_parts": args.front_parts,
                    "parallelism": f"batch split over {world} GPU(s), weights replicated, no collective"},
         "roofline": {"bound": bound,
                      "achieved": round(achieved, 2) if bound == "mfma" else round(g_gbps, 1),

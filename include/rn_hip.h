@@ -277,6 +277,11 @@ RN_API int rn_model_set_stem_exact(rn_model *m, int on);
  * changes.  Profiled and tuning forwards always use one stream.  Changing it invalidates the
  * tuned tiles. */
 RN_API int rn_model_set_streams(rn_model *m, int streams);
+/* parts = 1 (default), 2, 4, 8 or 16: the stem, the max-pool and the first stage -- the layers
+ * with the largest tensors -- run in that many slices of each batch part, one after the other,
+ * so that what one kernel writes is still in the 256 MB Infinity Cache when the next reads it;
+ * the other stages then run on the whole part.  Same bits.  Invalidates the tuned tiles. */
+RN_API int rn_model_set_front_parts(rn_model *m, int parts);
 RN_API int rn_model_set_profiling(rn_model *m, int on);
 /* after a profiled forward + rn_sync: number of ops, then one record per op */
 RN_API uint64_t rn_model_profile_count(const rn_model *m);

@@ -46,6 +46,7 @@ typedef struct {
     void *packed;                  /* K-major panel, model dtype */
     float *scale, *shift;          /* folded batch-norm */
     int tile;                      /* tuned contraction tile (0 = per-launch choice) */
+    uint64_t tile_B;               /* ... and the launch batch it was tuned at */
 } rn_conv;
 
 typedef struct {
@@ -57,6 +58,7 @@ typedef struct {
     void *pair_packed;
     float *pair_shift;
     int pair_tile;
+    uint64_t pair_tile_B;
 } rn_block;
 
 typedef struct {
@@ -107,12 +109,17 @@ struct rn_model {
     rn_ctx *ctxn[RN_MAX_STREAMS - 1];     /* contexts of parts 1.. (part 0 runs on ctx) */
     rn_event *ev_fork, *ev_join[RN_MAX_STREAMS - 1];
     int single_stream_only; /* tuning pass: its recorded calls are one half */
+    /* depth-first front: the stem, the pool and the first stage (the largest tensors) run in
+     * front_parts slices of the (sub-)batch, one after the other, so that what one kernel
+     * writes is still in the 256 MB Infinity Cache when the next reads it; the rest of the
+     * network then runs on the whole batch.  1 = off. */
+    int front_parts;
     /* what the ops of the sub-batch being queued run on: context, and views into the arenas */
     rn_ctx *run;
     struct { float *x4, *p0, *p1, *dsb, *t1, *t2, *pooled; } v;
     /* tile tuning: calls of the last forward, and the batch size the tiles were tuned for */
     rn_conv_call *calls;
-    int n_calls, recording;
+    int n_calls, cap_calls, recording;
     uint64_t tuned_B;
     int tuned_mode, cur_mode;
     /* profiling */
@@ -175,6 +182,7 @@ int rn_model_create(rn_ctx *ctx, rn_model **out, int arch)
     m = (rn_model *)calloc(1, sizeof(rn_model));
     if (m) m->pair_fusion = m->stem_exact = 1;
     if (m) m->streams = 2;
+    if (m) m->front_parts = 1;
     if (!m) return RN_ERR_NOMEM;
     m->ctx = ctx;
     m->arch = arch;
@@ -186,7 +194,8 @@ int rn_model_create(rn_ctx *ctx, rn_model **out, int arch)
     m->params = (rn_param *)calloc((size_t)max_convs * 5 + 2, sizeof(rn_param));
     m->convs = (rn_conv *)calloc((size_t)max_convs, sizeof(rn_conv));
     m->blocks = (rn_block *)calloc((size_t)total_blocks, sizeof(rn_block));
-    m->calls = (rn_conv_call *)calloc((size_t)max_convs, sizeof(rn_conv_call));
+    m->cap_calls = max_convs;
+    m->calls = (rn_conv_call *)calloc((size_t)m->cap_calls, sizeof(rn_conv_call));
     if (!m->params || !m->convs || !m->blocks || !m->calls) {
         rn_model_destroy(m);
         return RN_ERR_NOMEM;
@@ -507,6 +516,14 @@ int rn_model_set_streams(rn_model *m, int streams)
     return RN_OK;
 }
 
+int rn_model_set_front_parts(rn_model *m, int parts)
+{
+    if (!m || parts < 1 || parts > 16 || (parts & (parts - 1))) return RN_ERR_INVALID;
+    m->front_parts = parts;
+    m->tuned_B = 0;
+    return RN_OK;
+}
+
 int rn_model_set_stem_exact(rn_model *m, int on)
 {
     if (!m) return RN_ERR_INVALID;
@@ -592,6 +609,19 @@ int rn_model_profile_get(const rn_model *m, uint64_t index, const char **op_name
 /* pad_override >= 0 replaces the layer's padding (the bf16 stem reads an image that carries
  * its own zero border: H, W are then the padded sizes and the padding is 0); RN_PAD_EXACT: the
  * fp32 stem in its exact-K form, x = [B,H,W,cin] physically padded */
+/* next record of the tuning pass's call list (the slices of a depth-first front repeat calls) */
+static rn_conv_call *next_call(rn_model *m)
+{
+    if (m->n_calls == m->cap_calls) {
+        const int ncap = 2 * m->cap_calls + 16;
+        rn_conv_call *nc = (rn_conv_call *)realloc(m->calls, (size_t)ncap * sizeof(rn_conv_call));
+        if (!nc) return NULL;
+        m->calls = nc;
+        m->cap_calls = ncap;
+    }
+    return &m->calls[m->n_calls++];
+}
+
 #define RN_PAD_EXACT (-2)
 static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint64_t B, uint64_t H,
                    uint64_t W, const rn_epilogue *ep, int64_t pad_override)
@@ -606,7 +636,8 @@ static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint6
                          M * (double)cv->cout);
     if (ep && ep->residual) bytes += es * M * (double)cv->cout;
     if (m->recording) {
-        rn_conv_call *c = &m->calls[m->n_calls++];
+        rn_conv_call *c = next_call(m);
+        if (!c) return RN_ERR_NOMEM;
         c->conv = (int)(cv - m->convs);
         c->pair_block = -1;
         c->exact = exact;
@@ -621,7 +652,7 @@ static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint6
     }
     TRY(prof_begin(m, ep ? "conv2d+epilogue" : "conv2d", cv->name, 2.0 * M * (double)cv->cout * K,
                    bytes));
-    rn_ctx_set_conv_tile(m->run, (m->tuned_B == B && m->tuned_mode == m->cur_mode) ? cv->tile : 0);
+    rn_ctx_set_conv_tile(m->run, (m->tuned_B && cv->tile_B == B && m->tuned_mode == m->cur_mode) ? cv->tile : 0);
     {
         const int st =
             exact ? rn_conv2d_nhwc_exact_forward(m->run, (const float *)x, (float *)y,
@@ -652,7 +683,8 @@ static int op_pair(rn_model *m, rn_block *b, const void *t, const void *x, void 
     second.stride = cd->stride;
     ep.scale = NULL; ep.shift = b->pair_shift; ep.residual = NULL; ep.relu = 1;
     if (m->recording) {
-        rn_conv_call *c = &m->calls[m->n_calls++];
+        rn_conv_call *c = next_call(m);
+        if (!c) return RN_ERR_NOMEM;
         c->conv = b->conv3;
         c->pair_block = (int)(b - m->blocks);
         c->exact = 0;
@@ -663,7 +695,7 @@ static int op_pair(rn_model *m, rn_block *b, const void *t, const void *x, void 
     }
     snprintf(name, sizeof(name), "%.*s+downsample", (int)(RN_MAX_KEY - 12), c3->name);
     TRY(prof_begin(m, "conv2d+epilogue", name, 2.0 * M * (double)c3->cout * K, bytes));
-    rn_ctx_set_conv_tile(m->run, (m->tuned_B == B && m->tuned_mode == m->cur_mode) ? b->pair_tile : 0);
+    rn_ctx_set_conv_tile(m->run, (m->tuned_B && b->pair_tile_B == B && m->tuned_mode == m->cur_mode) ? b->pair_tile : 0);
     st = rn_conv2d_nhwc_pair_forward_dt(m->run, m->dtype, m->dtype, t, y, b->pair_packed, c3->k,
                                         c3->stride, c3->pad, H, W, B, c3->cin, c3->cout, H, W,
                                         &second, &ep);
@@ -750,9 +782,12 @@ static int block_forward(rn_model *m, rn_block *b, const float *x, float *y, uin
 int rn_ctx_wait_event(rn_ctx *ctx, rn_event *ev); /* rn_ctx.hip: the stream waits, not the host */
 
 /* B images whose activations live at image offset img_off of the arenas, queued on `run`. */
+enum { RN_PHASE_ALL = 0, RN_PHASE_FRONT = 1, RN_PHASE_BACK = 2 };
+
 static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *input_nchw,
-                       uint64_t B, float *logits, int mode)
+                       uint64_t B, float *logits, int mode, int phase)
 {
+    const int nfront = m->depths[0]; /* blocks of the front phase: the first stage */
     const rn_conv *stem;
     uint64_t H = 224, W = 224, ho, wo, ph, pw;
     float *x, *y, *tmp;
@@ -777,6 +812,18 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
         const double es = (double)elem_size(m);
         const int bf16 = m->dtype == RN_DTYPE_BF16;
         stem = &m->convs[0];
+        if (phase == RN_PHASE_BACK) {
+            /* the front ran already (in slices): x holds the first stage's output */
+            H = W = 56;
+            x = (nfront & 1) ? m->v.p1 : m->v.p0;
+            y = (nfront & 1) ? m->v.p0 : m->v.p1;
+            for (bi = nfront; bi < m->n_blocks; ++bi) {
+                STEP(block_forward(m, &m->blocks[bi], x, y, B, &H, &W, mode));
+                tmp = x; x = y; y = tmp;
+            }
+            if (st != RN_OK) break;
+            goto tail_ops;
+        }
         if (bf16) {
             /* bf16 stem: [B,230,230,4] image with its own 3-pixel zero border, padding 0 */
             const uint64_t border = stem->pad;
@@ -830,11 +877,12 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
         W = pw;
         x = m->v.p0;
         y = m->v.p1;
-        for (bi = 0; bi < m->n_blocks; ++bi) {
+        for (bi = 0; bi < (phase == RN_PHASE_FRONT ? nfront : m->n_blocks); ++bi) {
             STEP(block_forward(m, &m->blocks[bi], x, y, B, &H, &W, mode));
             tmp = x; x = y; y = tmp;
         }
-        if (st != RN_OK) break;
+        if (st != RN_OK || phase == RN_PHASE_FRONT) break;
+    tail_ops:
         /* global 7x7 average (main.cu:120,213) then fc (main.cu:122,224) */
         STEP(prof_begin(m, "avgpool2d", "avgpool", 0.0, es * (double)(B * 2048 * (H * W + 1))));
         STEP(rn_avgpool2d_nhwc_forward_dt(m->run, m->dtype, x, m->v.pooled, 7, 1, 0,
@@ -862,6 +910,24 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
 }
 
 #define RN_STREAM_MIN_PART 64
+#define RN_FRONT_MIN_SLICE 16
+
+/* B images at image offset img_off on `run`: whole, or depth-first through the front */
+static int forward_part(rn_model *m, rn_ctx *run, uint64_t img_off, const float *input_nchw,
+                        uint64_t B, float *logits, int mode)
+{
+    int fp = m->front_parts, j;
+    uint64_t lo = 0;
+    while (fp > 1 && B / (uint64_t)fp < RN_FRONT_MIN_SLICE) fp /= 2;
+    if (fp < 2) return forward_sub(m, run, img_off, input_nchw, B, logits, mode, RN_PHASE_ALL);
+    for (j = 0; j < fp; ++j) {
+        const uint64_t hi = B * (uint64_t)(j + 1) / (uint64_t)fp;
+        TRY(forward_sub(m, run, img_off + lo, input_nchw + lo * 3 * 224 * 224, hi - lo, logits, mode,
+                        RN_PHASE_FRONT));
+        lo = hi;
+    }
+    return forward_sub(m, run, img_off, input_nchw, B, logits, mode, RN_PHASE_BACK);
+}
 
 /* One sub-batch: every tensor of it stays below the kernels' 2^29-element range.  Large enough,
  * it runs as `streams` contiguous parts on as many streams (see rn_model.streams). */
@@ -873,7 +939,7 @@ static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float
     m->n_prof = 0;
     while (parts > 1 && B / (uint64_t)parts < RN_STREAM_MIN_PART) parts /= 2;
     if (parts < 2 || m->profiling || m->single_stream_only || m->recording)
-        return forward_sub(m, m->ctx, 0, input_nchw, B, logits, mode);
+        return forward_part(m, m->ctx, 0, input_nchw, B, logits, mode);
     if (!m->ev_fork) TRY(rn_event_create(m->ctx, &m->ev_fork));
     for (i = 0; i < parts - 1; ++i) {
         if (m->ctxn[i]) continue;
@@ -887,8 +953,8 @@ static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float
         const uint64_t hi = B * (uint64_t)(i + 1) / (uint64_t)parts;
         rn_ctx *run = i == 0 ? m->ctx : m->ctxn[i - 1];
         if (i > 0) TRY(rn_ctx_wait_event(run, m->ev_fork));
-        TRY(forward_sub(m, run, lo, input_nchw + lo * 3 * 224 * 224, hi - lo, logits + lo * RN_CLASSES,
-                        mode));
+        TRY(forward_part(m, run, lo, input_nchw + lo * 3 * 224 * 224, hi - lo, logits + lo * RN_CLASSES,
+                         mode));
         if (i > 0) TRY(rn_event_record(run, m->ev_join[i - 1]));
         lo = hi;
     }
@@ -949,7 +1015,11 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
         const uint64_t ho = rn_conv_output_size(k->H, cv->k, cv->stride, k->pad);
         const uint64_t wo = rn_conv_output_size(k->W, cv->k, cv->stride, k->pad);
         float best = 1e30f;
-        int best_c = 0;
+        int best_c = 0, seen = 0, j;
+        for (j = 0; j < i; ++j) /* the slices of a depth-first front repeat their calls */
+            seen |= m->calls[j].conv == k->conv && m->calls[j].pair_block == k->pair_block &&
+                    m->calls[j].B == k->B;
+        if (seen) continue;
         for (c = 0; c <= ncand && st == RN_OK; ++c) { /* 0 = the per-launch choice itself */
             float ms = 1e30f;
             rn_ctx_set_conv_tile(m->ctx, c);
@@ -984,10 +1054,13 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
                 best_c = c;
             }
         }
-        if (k->pair_block >= 0)
+        if (k->pair_block >= 0) {
             m->blocks[k->pair_block].pair_tile = best_c;
-        else
+            m->blocks[k->pair_block].pair_tile_B = k->B;
+        } else {
             cv->tile = best_c;
+            cv->tile_B = k->B;
+        }
     }
     rn_ctx_set_conv_tile(m->ctx, 0);
     rn_event_destroy(e0);

@@ -270,6 +270,10 @@ class NativeModel:
         """2 (default): batches of >= 128 images run as two halves on two streams; 1: one stream."""
         L.check(L.lib().rn_model_set_streams(self.handle, int(streams)), "rn_model_set_streams")
 
+    def set_front_parts(self, parts: int) -> None:
+        """Stem, max-pool and first stage in `parts` slices of the batch (Infinity-Cache reuse)."""
+        L.check(L.lib().rn_model_set_front_parts(self.handle, int(parts)), "rn_model_set_front_parts")
+
     def set_stem_exact(self, on: bool) -> None:
         """fp32: stem in the exact-K form (K = 160, default) or the 4-channel slot form (224)."""
         L.check(L.lib().rn_model_set_stem_exact(self.handle, int(on)), "rn_model_set_stem_exact")

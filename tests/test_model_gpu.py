@@ -285,6 +285,40 @@ def test_batch_larger_than_one_launch_can_address_runs_as_sub_batches(model50, f
     del xin, out
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_streams_and_depth_first_front_change_speed_not_results(state50, finch, dtype):
+    """rn_model_set_streams (a batch as parts on streams of their own) and
+    rn_model_set_front_parts (stem + max-pool + first stage in slices, for Infinity-Cache reuse)
+    reschedule the same launches on sub-batches: bit-identical logits, also after tuning (the
+    tuned tile of a layer is remembered with the launch batch it was tuned at)."""
+    m = R.NativeModel("resnet50", state=state50, dtype=dtype)
+    try:
+        B = 128
+        x = R.weights.generate_input(B, seed=66)
+        x[77] = finch[0]
+        m.set_streams(1)
+        base = m.forward(x, fused=True)
+        assert np.array_equal(base[77:78], m.forward(finch, fused=True))
+        for streams, front in ((2, 1), (1, 4), (2, 4), (4, 2), (1, 8)):
+            m.set_streams(streams)
+            m.set_front_parts(front)
+            assert np.array_equal(m.forward(x, fused=True), base), (streams, front)
+        xin = R.FloatTensor.from_numpy(x, R.Device.GPU)
+        out = R.FloatTensor((B, 1000), R.Device.GPU)
+        m.set_streams(2)
+        m.set_front_parts(2)
+        m.tune(xin.data(), B, out.data(), fused=True)
+        m.ctx.sync()
+        assert np.array_equal(out.numpy(), base)
+        assert np.array_equal(m.forward(x, fused=True), base)
+        with pytest.raises(R.RnError):
+            m.set_front_parts(3)
+        with pytest.raises(R.RnError):
+            m.set_streams(3)
+    finally:
+        m.close()
+
+
 def test_sharded_model_equals_whole_batch(state50, model50, finch):
     """rn_shard_*: one host thread + context + model per listed device, contiguous batch split,
     logits concatenated on the host (main.cu:228-254 over several devices).  A
