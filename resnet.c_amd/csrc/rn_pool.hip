@@ -174,6 +174,63 @@ __global__ __launch_bounds__(kBlock) void pool_nhwc_bf16_kernel(
     }
 }
 
+// 3x3 max-pool whose every window holds at least one real pixel (the network's pool after the
+// stem, ops.cu:50-78 with k 3, stride 2, padding 1).  A padded tap is replaced by the nearest
+// pixel inside the image, which is a tap of the same window already, so the maximum -- NaN
+// rules of fmaxf included -- is the reference's; and then the nine 16-byte loads of a lane
+// need no bounds branch and are all in flight together.  E x N = float x 4 or bf16 x 8.
+template <typename E, int N>
+__global__ __launch_bounds__(kBlock) void maxpool3_nhwc_kernel(const void *__restrict__ inp, void *__restrict__ outp,
+                                                               int stride, int pad, int Ho, int Wo, int CV,
+                                                               int H, int W, uint64_t total)
+{
+    typedef E V __attribute__((ext_vector_type(N)));
+    const V *in = static_cast<const V *>(inp);
+    V *out = static_cast<V *>(outp);
+    const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i64 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i64 < total; i64 += gstride) {
+        const uint32_t i = (uint32_t)i64;
+        const int cv = (int)(i % (uint32_t)CV);
+        uint32_t pix = i / (uint32_t)CV;
+        const int ow = (int)(pix % (uint32_t)Wo);
+        pix /= (uint32_t)Wo;
+        const int oh = (int)(pix % (uint32_t)Ho);
+        const uint64_t b = pix / (uint32_t)Ho;
+        const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+        int rows[3], cols[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            rows[t] = min(max(ih0 + t, 0), H - 1);
+            cols[t] = min(max(iw0 + t, 0), W - 1);
+        }
+        V v[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                v[3 * kh + kw] = in[((b * H + rows[kh]) * W + cols[kw]) * CV + cv];
+        float acc[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)  // tap order kh -> kw, as the reference
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[j] = fmaxf(acc[j], (float)v[t][j]);
+        V o;
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] = (E)acc[j];
+        __builtin_nontemporal_store(o, &out[i64]);
+    }
+}
+
+// every window of the pooling geometry holds a real pixel, in both dimensions
+static bool windows_never_empty(uint64_t k, uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out,
+                                uint64_t H, uint64_t W)
+{
+    return pad < k && h_out >= 1 && w_out >= 1 && (h_out - 1) * stride < H + pad &&
+           (w_out - 1) * stride < W + pad;
+}
+
 template <bool kMax>
 int pool_bf16_dispatch(rn_ctx *ctx, const void *inp, void *out, uint64_t k, uint64_t stride,
                        uint64_t pad, uint64_t h_out, uint64_t w_out, uint64_t B, uint64_t C,
@@ -189,6 +246,11 @@ int pool_bf16_dispatch(rn_ctx *ctx, const void *inp, void *out, uint64_t k, uint
     RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
                "bf16 tensors must be 16-byte aligned");
     const uint64_t total8 = total / 8;
+    if (kMax && k == 3 && windows_never_empty(k, stride, pad, h_out, w_out, H, W)) {
+        maxpool3_nhwc_kernel<bf16_t, 8><<<rn_stream_grid(total8, kBlock), kBlock, 0, ctx->stream>>>(
+            inp, out, (int)stride, (int)pad, (int)h_out, (int)w_out, (int)(C / 8), (int)H, (int)W, total8);
+        return rn_after_launch(ctx, what);
+    }
     pool_nhwc_bf16_kernel<kMax><<<rn_stream_grid(total8, kBlock), kBlock, 0, ctx->stream>>>(
         (const bf16_t *)inp, (bf16_t *)out, (int)k, (int)stride, (int)pad, (int)h_out, (int)w_out,
         (int)(C / 8), (int)H, (int)W, total8);
@@ -214,6 +276,11 @@ int pool_dispatch(rn_ctx *ctx, const float *inp, float *out, uint64_t k, uint64_
                     0;
     if (ctx->layout == RN_LAYOUT_NHWC && al && C % 4 == 0 && total / 4 < (1ull << 32)) {
         const uint64_t total4 = total / 4;
+        if (kMax && k == 3 && windows_never_empty(k, stride, pad, h_out, w_out, H, W)) {
+            maxpool3_nhwc_kernel<float, 4><<<rn_stream_grid(total4, kBlock), kBlock, 0, ctx->stream>>>(
+                inp, out, (int)stride, (int)pad, (int)h_out, (int)w_out, (int)(C / 4), (int)H, (int)W, total4);
+            return rn_after_launch(ctx, what);
+        }
         pool_nhwc_vec_kernel<kMax><<<rn_stream_grid(total4, kBlock), kBlock, 0, ctx->stream>>>(
             inp, out, (int)k, (int)stride, (int)pad, (int)h_out, (int)w_out, (int)(C / 4), (int)H,
             (int)W, total4);
