@@ -208,8 +208,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the PCIe-inclusive leg")
     ap.add_argument("--no-tune", action="store_true", help="skip the per-layer tile tuning pass")
-    ap.add_argument("--streams", type=int, default=2, choices=[1, 2, 4],
-                    help="parts of a batch that run on streams of their own (they fill each other's kernel tails)")
+    ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2, 4],
+                    help="parts of a batch that run on streams of their own (they fill each other's kernel "
+                         "tails); 0 = the library's default: 1 for fp32 (+0.5 %% is not worth blurring the "
+                         "per-kernel times), 2 for bf16 storage (+9 %%)")
     ap.add_argument("--front-parts", type=int, default=1,
                     help="stem + max-pool + first stage in this many slices per batch part (Infinity-Cache reuse)")
     ap.add_argument("--profile-forwards", type=int, default=3)
@@ -248,7 +250,9 @@ def main():
     B = args.batch
     state = R.weights.generate_state(args.arch, seed=0)
     model = R.NativeModel(args.arch, state=state, ctx=ctx, dtype=args.dtype)
-    model.set_streams(args.streams)
+    if args.streams:
+        model.set_streams(args.streams)
+    args.streams = model.streams()
     model.set_front_parts(args.front_parts)
     lo, hi = shard_bounds(world * B, rank, world)
     # this rank's shard of the global batch: image i depends on (seed, i) only
@@ -361,7 +365,11 @@ def main():
                      "ops_per_forward": g_ops, "launches_per_forward": g_launch,
                      "avg_launch_us": round(g_ms * 1e3 / max(g_launch, 1), 2),
                      "flops_per_forward": g_flops, "bytes_per_forward": g_bytes,
-                     "ms_per_forward": round(g_ms, 4)},
+                     "ms_per_forward": round(g_ms, 4),
+                     "measured_on": "HIP events around every op of %d instrumented forwards right after the "
+                                    "timed region, whole batch on ONE stream (with streams_per_gpu > 1 the timed "
+                                    "region overlaps the kernels of the batch parts, so their sum exceeds "
+                                    "ms_per_step)" % args.profile_forwards},
         "world": {"size": dist_world, "backend": dist_backend, "ranks": ranks},
         "whole_step_mfma_frac": round(value / world * GFLOP_PER_IMAGE[args.arch] / 1e3 / peak, 4),
         "hbm_kernels": hbm,

@@ -271,12 +271,15 @@ RN_API int rn_model_set_pair_fusion(rn_model *m, int on);
 /* fp32 models: stem through rn_conv2d_nhwc_exact_forward (K = 160; default) or through the
  * 4-channel / 8-slot form of rn_conv2d_nhwc_forward (K = 224).  Invalidates the tuned tiles. */
 RN_API int rn_model_set_stem_exact(rn_model *m, int on);
-/* streams = 1, 2 (default) or 4: a (sub-)batch runs as that many contiguous parts (of at least
- * 64 images each) on streams of their own -- the launches of one part fill the tails of the
- * others'; every image's logits are independent of what else is in its launch, so no bit
- * changes.  Profiled and tuning forwards always use one stream.  Changing it invalidates the
+/* streams = 1, 2 or 4: a (sub-)batch runs as that many contiguous parts (of at least 64 images
+ * each) on streams of their own -- the launches of one part fill the tails of the others';
+ * every image's logits are independent of what else is in its launch, so no bit changes.
+ * Default: 1 for fp32 models (measured +0.5 %), 2 for bf16 storage (+9 %: its 256-wide tiles
+ * leave CUs idle in the late stages); rn_model_set_dtype applies the default unless this was
+ * called.  Profiled and tuning forwards always use one stream.  Changing it invalidates the
  * tuned tiles. */
 RN_API int rn_model_set_streams(rn_model *m, int streams);
+RN_API int rn_model_get_streams(const rn_model *m);
 /* parts = 1 (default), 2, 4, 8 or 16: the stem, the max-pool and the first stage -- the layers
  * with the largest tensors -- run in that many slices of each batch part, one after the other,
  * so that what one kernel writes is still in the 256 MB Infinity Cache when the next reads it;
@@ -306,6 +309,24 @@ RN_API int rn_conv2d_nhwc_exact_forward(rn_ctx *ctx, const float *inp_padded, fl
                                         uint64_t stride, uint64_t h_out, uint64_t w_out,
                                         uint64_t B, uint64_t in_channels, uint64_t out_channels,
                                         uint64_t Hp, uint64_t Wp, const rn_epilogue *epilogue);
+
+/* ---- fused stem: conv 7x7/2 + folded batch-norm + ReLU + max-pool 3x3/2/1 in one launch ----
+ * The first four ops of the reference's forward (main.cu:179-192) without ever writing the
+ * 112x112x64 stem tensor: a direct convolution out of an LDS-resident input patch, the pool as
+ * LDS integer maxima of the non-negative ReLU outputs.  inp_padded: NHWC image that carries its
+ * own 3-pixel zero border (rn_nchw_to_nhwc_pad_dt with border 3; Cpad = 3 for fp32, 4 for
+ * bf16), [B,Hp,Wp,Cpad]; out: [B,PH,PW,64] of `dtype`.  Needs 64 output channels, a conv
+ * output width that is a multiple of 8 and at most 128 (ResNet: 112).  scale/shift: per
+ * channel, nullable.  Same products as conv + bn + relu + maxpool, summed in another order. */
+RN_API uint64_t rn_stem_pool_packed_weight_numel(int dtype);
+RN_API int rn_stem_pool_pack_weight_dt(rn_ctx *ctx, int dtype, const float *weight_oihw /* [64,Cin,7,7] */,
+                                       void *packed, uint64_t in_channels);
+RN_API int rn_stem_pool_forward_dt(rn_ctx *ctx, int dtype, const void *inp_padded, void *out,
+                                   const void *packed_weight, const float *scale, const float *shift,
+                                   int relu, uint64_t B, uint64_t Hp, uint64_t Wp);
+/* Fused mode: use it for conv1 + bn1 + relu + maxpool (default on; fp32 needs the exact-K stem
+ * image, rn_model_set_stem_exact).  Invalidates the tuned tiles. */
+RN_API int rn_model_set_stem_pool_fusion(rn_model *m, int on);
 
 /* ---- fused pair: out = epilogue(conv(inp, W1) + conv1x1(inp2, W2)) ------------------
  * One contraction whose K loop runs through both convolutions: the bottleneck's conv3 and the

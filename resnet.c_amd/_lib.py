@@ -100,7 +100,12 @@ SIGNATURES = {
                                        + [POINTER(ConvSecond), POINTER(Epilogue)]),
     "rn_model_set_pair_fusion": (c_int, [c_void_p, c_int]),
     "rn_model_set_stem_exact": (c_int, [c_void_p, c_int]),
+    "rn_stem_pool_packed_weight_numel": (u64, [c_int]),
+    "rn_stem_pool_pack_weight_dt": (c_int, [c_void_p, c_int, fptr, fptr, u64]),
+    "rn_stem_pool_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr, fptr, fptr, fptr, c_int, u64, u64, u64]),
+    "rn_model_set_stem_pool_fusion": (c_int, [c_void_p, c_int]),
     "rn_model_set_streams": (c_int, [c_void_p, c_int]),
+    "rn_model_get_streams": (c_int, [c_void_p]),
     "rn_model_set_front_parts": (c_int, [c_void_p, c_int]),
     "rn_maxpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),
     "rn_avgpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),

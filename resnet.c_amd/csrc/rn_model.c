@@ -96,6 +96,8 @@ struct rn_model {
     int pair_fusion;  /* fused mode: conv3 + downsample as one contraction (default on) */
     int stem_exact;   /* fp32: stem in the exact-K form, K = 160 instead of 224 (default on) */
     float *stem_packed_exact;
+    int stem_pool;           /* fused mode: stem + batch-norm + ReLU + max-pool as one launch (default on) */
+    void *stem_pool_packed;  /* its weight panel, model dtype */
     void *fc_packed;  /* fc.weight in the model dtype (bf16 models only) */
     /* activation arenas, sized for batch_cap images */
     uint64_t batch_cap;
@@ -108,6 +110,7 @@ struct rn_model {
     int streams;            /* parts a sub-batch is split into (each >= RN_STREAM_MIN_PART images) */
     rn_ctx *ctxn[RN_MAX_STREAMS - 1];     /* contexts of parts 1.. (part 0 runs on ctx) */
     rn_event *ev_fork, *ev_join[RN_MAX_STREAMS - 1];
+    int streams_set;        /* rn_model_set_streams was called: keep it whatever the dtype */
     int single_stream_only; /* tuning pass: its recorded calls are one half */
     /* depth-first front: the stem, the pool and the first stage (the largest tensors) run in
      * front_parts slices of the (sub-)batch, one after the other, so that what one kernel
@@ -181,7 +184,8 @@ int rn_model_create(rn_ctx *ctx, rn_model **out, int arch)
     else return RN_ERR_UNSUPPORTED;
     m = (rn_model *)calloc(1, sizeof(rn_model));
     if (m) m->pair_fusion = m->stem_exact = 1;
-    if (m) m->streams = 2;
+    if (m) m->streams = 1;
+    if (m) m->stem_pool = 1;
     if (m) m->front_parts = 1;
     if (!m) return RN_ERR_NOMEM;
     m->ctx = ctx;
@@ -285,6 +289,7 @@ int rn_model_destroy(rn_model *m)
     }
     rn_free(m->ctx, m->fc_packed);
     rn_free(m->ctx, m->stem_packed_exact);
+    rn_free(m->ctx, m->stem_pool_packed);
     free_acts(m);
     free_prof(m);
     {
@@ -362,6 +367,7 @@ int rn_model_set_dtype(rn_model *m, int dtype)
 {
     int c;
     if (!m || (dtype != RN_DTYPE_F32 && dtype != RN_DTYPE_BF16)) return RN_ERR_INVALID;
+    if (!m->streams_set) m->streams = dtype == RN_DTYPE_BF16 ? 2 : 1; /* measured defaults */
     if (dtype == m->dtype) return RN_OK;
     /* packed panels and arenas depend on the element size: drop them */
     for (c = 0; c < m->n_convs; ++c) {
@@ -376,6 +382,8 @@ int rn_model_set_dtype(rn_model *m, int dtype)
     }
     rn_free(m->ctx, m->fc_packed);
     m->fc_packed = NULL;
+    rn_free(m->ctx, m->stem_pool_packed);
+    m->stem_pool_packed = NULL;
     free_acts(m);
     m->dtype = dtype;
     m->finalized = 0;
@@ -422,6 +430,15 @@ int rn_model_finalize(rn_model *m)
         }
         st = rn_conv2d_pack_weight_exact(m->ctx, m->params[stem->w].dev, m->stem_packed_exact,
                                          stem->cin, stem->cout, stem->k);
+        if (st != RN_OK) return st;
+    }
+    {   /* panel of the fused stem + max-pool launch */
+        const rn_conv *stem = &m->convs[0];
+        if (!m->stem_pool_packed) {
+            st = rn_malloc(m->ctx, &m->stem_pool_packed, rn_stem_pool_packed_weight_numel(m->dtype) * elem_size(m));
+            if (st != RN_OK) return st;
+        }
+        st = rn_stem_pool_pack_weight_dt(m->ctx, m->dtype, m->params[stem->w].dev, m->stem_pool_packed, stem->cin);
         if (st != RN_OK) return st;
     }
     for (c = 0; c < m->n_blocks; ++c) {
@@ -512,7 +529,18 @@ int rn_model_set_streams(rn_model *m, int streams)
 {
     if (!m || (streams != 1 && streams != 2 && streams != 4)) return RN_ERR_INVALID;
     m->streams = streams;
+    m->streams_set = 1;
     m->tuned_B = 0; /* the launches change size */
+    return RN_OK;
+}
+
+int rn_model_get_streams(const rn_model *m) { return m ? m->streams : 0; }
+
+int rn_model_set_stem_pool_fusion(rn_model *m, int on)
+{
+    if (!m) return RN_ERR_INVALID;
+    m->stem_pool = on ? 1 : 0;
+    m->tuned_B = 0;
     return RN_OK;
 }
 
@@ -727,6 +755,24 @@ static int op_add(rn_model *m, const char *layer, float *y, const float *shortcu
     return prof_end(m);
 }
 
+/* conv1 + bn1 + ReLU + max-pool (main.cu:179-192) as one launch: x4 (physically padded image)
+ * -> p0 (pooled, where the separate max-pool writes too).  Algorithmic work: the stem's FLOPs
+ * (no halo), the image read once, the pooled tensor written once. */
+static int op_stem_pool(rn_model *m, const rn_conv *stem, uint64_t B, uint64_t Hp, uint64_t Wp,
+                        uint64_t ho, uint64_t wo)
+{
+    const double es = (double)elem_size(m);
+    const uint64_t ph = rn_conv_output_size(ho, 3, 2, 1), pw = rn_conv_output_size(wo, 3, 2, 1);
+    const double cs = m->dtype == RN_DTYPE_BF16 ? 4.0 : 3.0;
+    TRY(prof_begin(m, "conv2d+epilogue+maxpool", "conv1+maxpool",
+                   2.0 * (double)(B * ho * wo) * (double)stem->cout * (double)(stem->cin * stem->k * stem->k),
+                   es * ((double)(B * Hp * Wp) * cs + (double)(stem->cout * stem->cin * stem->k * stem->k) +
+                         (double)(B * ph * pw * stem->cout))));
+    TRY(rn_stem_pool_forward_dt(m->run, m->dtype, m->v.x4, m->v.p0, m->stem_pool_packed, stem->scale,
+                                stem->shift, 1, B, Hp, Wp));
+    return prof_end(m);
+}
+
 /* one bottleneck block (layerForward body, main.cu:131-164).  x -> y, both NHWC. */
 static int block_forward(rn_model *m, rn_block *b, const float *x, float *y, uint64_t B,
                          uint64_t *H, uint64_t *W, int mode)
@@ -788,6 +834,7 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
                        uint64_t B, float *logits, int mode, int phase)
 {
     const int nfront = m->depths[0]; /* blocks of the front phase: the first stage */
+    int fused_pool = 0;
     const rn_conv *stem;
     uint64_t H = 224, W = 224, ho, wo, ph, pw;
     float *x, *y, *tmp;
@@ -833,7 +880,10 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
             STEP(prof_end(m));
             ho = rn_conv_output_size(H + 2 * border, stem->k, stem->stride, 0);
             wo = rn_conv_output_size(W + 2 * border, stem->k, stem->stride, 0);
-            {
+            if (m->stem_pool) {
+                STEP(op_stem_pool(m, stem, B, H + 2 * border, W + 2 * border, ho, wo));
+                fused_pool = 1;
+            } else {
                 rn_epilogue ep;
                 ep.scale = stem->scale; ep.shift = stem->shift; ep.residual = NULL; ep.relu = 1;
                 STEP(op_conv(m, stem, m->v.x4, m->v.p1, B, H + 2 * border, W + 2 * border, &ep, 0));
@@ -855,7 +905,10 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
             STEP(prof_end(m));
             ho = rn_conv_output_size(H, stem->k, stem->stride, stem->pad);
             wo = rn_conv_output_size(W, stem->k, stem->stride, stem->pad);
-            if (mode == RN_FWD_FUSED) {
+            if (mode == RN_FWD_FUSED && m->stem_pool && m->stem_exact) {
+                STEP(op_stem_pool(m, stem, B, sh, sw, ho, wo));
+                fused_pool = 1;
+            } else if (mode == RN_FWD_FUSED) {
                 rn_epilogue ep;
                 ep.scale = stem->scale; ep.shift = stem->shift; ep.residual = NULL; ep.relu = 1;
                 STEP(op_conv(m, stem, m->v.x4, m->v.p1, B, sh, sw, &ep, form));
@@ -868,11 +921,13 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
         /* maxpool 3x3 s2 p1 (main.cu:114,192) */
         ph = rn_conv_output_size(ho, 3, 2, 1);
         pw = rn_conv_output_size(wo, 3, 2, 1);
-        STEP(prof_begin(m, "maxpool2d", "maxpool", 0.0,
-                        es * (double)(B * 64 * (ho * wo + ph * pw))));
-        STEP(rn_maxpool2d_nhwc_forward_dt(m->run, m->dtype, m->v.p1, m->v.p0, 3, 2, 1, ph, pw, B, 64, ho,
-                                          wo));
-        STEP(prof_end(m));
+        if (!fused_pool) {
+            STEP(prof_begin(m, "maxpool2d", "maxpool", 0.0,
+                            es * (double)(B * 64 * (ho * wo + ph * pw))));
+            STEP(rn_maxpool2d_nhwc_forward_dt(m->run, m->dtype, m->v.p1, m->v.p0, 3, 2, 1, ph, pw, B, 64, ho,
+                                              wo));
+            STEP(prof_end(m));
+        }
         H = ph;
         W = pw;
         x = m->v.p0;

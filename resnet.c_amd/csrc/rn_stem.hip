@@ -1,0 +1,396 @@
+// Stem in one launch: conv 7x7 stride 2 (3 -> 64 channels) + folded batch-norm + ReLU + max-pool
+// 3x3 stride 2 padding 1.  Reference: the first four ops of resnet152Forward
+// (cuda/inference/main.cu:179-192 -> conv2dForwardKernel ops.cu:14-48, batchNorm2dForwardKernel
+// ops.cu:139-151, reluForwardKernel ops.cu:130-137, maxPool2dKernel ops.cu:50-78).
+//
+// As an implicit GEMM the stem is a bad fit: K = 147, N = 64, and every input pixel is gathered
+// ~12 times from L2 in 64-byte pieces (the contraction kernel spends 0.72 ms fp32 / 0.30 ms bf16
+// on 0.38 / 0.08 ms of matrix work), after which its 112x112x64 output -- the largest tensor of
+// the network -- goes to HBM only to be read back by the pool.  Here:
+//
+//  * a block owns two pooled rows of one image: stem rows 2*ph0-1 .. 2*ph0+3 (five rows, one of
+//    them a halo recomputed by the next block: +25 % matrix work) x all columns x 64 channels;
+//  * the input patch those rows need -- 15 rows of the physically padded NHWC image, one
+//    contiguous block of memory -- is copied to LDS once; the MFMA A operands are read
+//    straight out of it: for fixed kernel row, the k index runs over (kw, c) = consecutive
+//    floats / bf16 of the patch row, so a fragment is one ds_read_b32 (fp32, 32x32x2 MFMA) or
+//    one ds_read_b128 (bf16, 32x32x16 MFMA) at base(position) + constant(k-step).  No im2col;
+//  * the weights live in registers for the lifetime of the (persistent) block: 77 floats or
+//    14 x 8 bf16 per lane, one 32-channel half per wave;
+//  * K order: kernel row major; fp32 (kw, c) with one zero-weight slot per row (22 per row, 154);
+//    bf16 (kw pair, kw parity, c of 4) with kw = 7 and c = 3 zero-weight (32 per row, 224);
+//  * epilogue in registers: y = max(acc * scale + shift, 0) (bf16: rounded to bf16), then the
+//    max-pool: the vertical part in registers (an M tile is 4 stem rows x 8 columns, so a lane
+//    holds four rows of four adjacent columns of its channel), the rest as LDS integer maxima:
+//    y >= 0, so its bit pattern orders like the value and ds_max_u32 into a zeroed [2][PW][64]
+//    buffer gives exactly the reference's maximum over the window's real pixels (every window
+//    has one; padded taps are skipped, ops.cu:65-67);
+//  * the pooled rows leave as whole 128..256-byte pixels.  The stem tensor is never written.
+//
+// Bound: matrix pipe in fp32 (0.50 ms at peak for B=256 with the halo), HBM in bf16 (0.3 GB).
+#include <type_traits>
+
+#include "rn_conv_params.h"
+
+using namespace rn_gemm;
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kCout = 64, kK = 7;
+constexpr int kPatchRows = 15;  // input rows behind five stem rows: 2*4 + 7
+constexpr int kMaxTiles = 5;    // 32-position M tiles per wave (4 wave rows): Wo <= 128
+
+struct StemParams {
+    const void *in;      // [B][Hp][Wp][CS] physically padded NHWC image (CS = 3 fp32, 4 bf16)
+    const void *w;       // packed panel, see rn_stem_pool_pack_weight_dt
+    const float *scale;  // folded batch-norm, may be null
+    const float *shift;
+    void *out;           // [B][PH][PW][64]
+    int B, Hp, Wp, Ho, Wo, PH, PW;
+    int relu;
+    unsigned items;      // B * ceil(PH / 2)
+    int pairs;           // ceil(PH / 2)
+};
+
+template <typename T>
+struct Cfg;
+template <>
+struct Cfg<float> {
+    static constexpr int CS = 3;        // channels per pixel in memory
+    static constexpr int KROW = 22;     // k per kernel row (21 + one zero-weight slot)
+    static constexpr int KPS = 2;       // k per MFMA step
+    static constexpr int STEPS_ROW = 11;
+};
+template <>
+struct Cfg<bf16_t> {
+    static constexpr int CS = 4;
+    static constexpr int KROW = 32;
+    static constexpr int KPS = 16;
+    static constexpr int STEPS_ROW = 2;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
+{
+    using C = Cfg<T>;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int PIXB = C::CS * ES;            // bytes per pixel: 12 / 8
+    constexpr int STEPS = kK * C::STEPS_ROW;    // MFMA k-steps: 77 / 14
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int rowb = p.Wp * PIXB;               // bytes per patch row
+    const int patch_bytes = 48 + ((kPatchRows * rowb + 15) & ~15);  // slack: shifted base in front, piece overhang behind
+    float *const pooled = reinterpret_cast<float *>(lds + patch_bytes);  // [2][PW][64]
+    const int pooled_n = 2 * p.PW * kCout;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n = wn * 32 + li;  // this lane's output channel
+    const int n2d = p.Wo >> 3, ntiles = n2d + ((p.Wo + 31) >> 5);  // 4x8 tiles of rows 0..3, 1x32 tiles of row 4
+
+    // weights of this lane's channel: B operand of every k-step, loaded once
+    typename std::conditional<sizeof(T) == 4, float, i32x4>::type bw[STEPS];
+    {
+        const char *wrow = static_cast<const char *>(p.w) + (size_t)n * (kK * C::KROW) * ES;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            if constexpr (sizeof(T) == 4)
+                bw[s] = *reinterpret_cast<const float *>(wrow + (s * 2 + lh) * 4);
+            else
+                bw[s] = *reinterpret_cast<const i32x4 *>(wrow + (s * 16 + lh * 8) * 2);
+        }
+    }
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float sh = p.shift ? p.shift[n] : 0.f;
+
+    for (int i = t; i < pooled_n; i += 512) pooled[i] = 0.f;
+
+    // The input patch of an item: rows [row0, row0 + 15) of the padded image clipped to the image --
+    // one contiguous block of memory -- fetched as 16-byte pieces from the 16-byte boundary below
+    // its first byte (fp32 rows are only 8-byte multiples; the LDS image is shifted likewise, it
+    // starts 16 or 24 bytes into the array).  All pieces of a thread are independent loads, issued for
+    // item i+1 before the contraction of item i and written to LDS after it: the fetch hides
+    // behind the matrix work instead of standing in front of it.
+    constexpr int kPieces = 6;  // 512 threads x 16 B x 6 = 48 KB >= 15 rows of 266 fp32 pixels
+    i32x4 stage[kPieces];
+    auto patch_src = [&](unsigned item, const char *&src, int &dst_off, int &nbytes, int &base) {
+        const int b = (int)(item / (unsigned)p.pairs), pj = (int)(item % (unsigned)p.pairs);
+        const int row0 = 2 * (4 * pj - 1);
+        const int lo = max(row0, 0), hi = min(row0 + kPatchRows, p.Hp);
+        const char *first = static_cast<const char *>(p.in) + ((size_t)b * p.Hp + lo) * rowb;
+        const int mis = (int)(reinterpret_cast<uintptr_t>(first) & 15);
+        src = first - mis;
+        // LDS offset of patch row 0: 16 or 24, whichever puts the first fetched piece on a
+        // 16-byte boundary
+        base = 16 + ((mis - (lo - row0) * rowb) & 15);
+        dst_off = base + (lo - row0) * rowb - mis;
+        nbytes = (hi - lo) * rowb + mis;
+    };
+    auto patch_fetch = [&](unsigned item) {
+        const char *src;
+        int dst_off, nbytes, base;
+        patch_src(item, src, dst_off, nbytes, base);
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k) {
+            const int o = (k * 512 + t) * 16;
+            stage[k] = *reinterpret_cast<const i32x4 *>(src + (o < nbytes ? o : 0));
+        }
+    };
+    auto patch_store = [&](unsigned item) -> int {
+        const char *src;
+        int dst_off, nbytes, base;
+        patch_src(item, src, dst_off, nbytes, base);
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k) {
+            const int o = (k * 512 + t) * 16;
+            if (o < nbytes) *reinterpret_cast<i32x4 *>(lds + dst_off + o) = stage[k];
+        }
+        return base;
+    };
+
+    if (blockIdx.x < p.items) patch_fetch(blockIdx.x);
+    for (unsigned item = blockIdx.x; item < p.items; item += gridDim.x) {
+        const int b = (int)(item / (unsigned)p.pairs), pj = (int)(item % (unsigned)p.pairs);
+        const int ph0 = 2 * pj;
+        const int oh_first = 2 * ph0 - 1;     // stem row of r = 0 (-1 for the first pair: no such row)
+        const char *const patch = lds + patch_store(item);  // patch row 0
+        __syncthreads();
+        if (item + gridDim.x < p.items) patch_fetch(item + gridDim.x);
+
+        // Per-item copies of the lane / wave coordinates that the compiler cannot see through:
+        // everything below depends only on them and on the kernel arguments, and hoisted out of
+        // the item loop (385 fragment addresses, the epilogue's index arithmetic) it costs more
+        // than a thousand spilled registers.
+        int li_ = li, lh_ = lh, wm_ = wm;
+        asm volatile("" : "+v"(li_), "+v"(lh_), "+s"(wm_));
+
+        // ---- contraction: wave (wm, wn) owns M tiles wm, wm+4, ... and channels 32*wn ..
+        // M tiles: n2d tiles of 4 stem rows (r = 0..3) x 8 columns -- lane li is (row li>>3, column
+        // li&7) -- then n1d tiles of 32 columns of stem row r = 4.  In the accumulator of a 4x8
+        // tile a lane then holds, for its channel, rows 0..3 of four adjacent columns (element e:
+        // row e>>2, column 4*lh + (e&3)): the vertical part of the pool happens in registers.
+        f32x16 acc[kMaxTiles];
+        int abase[kMaxTiles];
+#pragma unroll
+        for (int j = 0; j < kMaxTiles; ++j) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+            const int tile = wm_ + 4 * j;
+            const bool two_d = tile < n2d;
+            const int r = two_d ? li_ >> 3 : 4;
+            const int ox = two_d ? 8 * tile + (li_ & 7) : 32 * (tile - n2d) + li_;
+            // patch row 2r + kh, pixel 2*ox + kw; the lane half takes the upper half of a k-step
+            abase[j] = ox < p.Wo ? 2 * r * rowb + 2 * ox * PIXB + lh_ * (C::KPS / 2) * ES : 0;
+        }
+#pragma unroll
+        for (int kh = 0; kh < kK; ++kh) {
+            int arow[kMaxTiles];  // this kernel row's fragment base; the k-steps are immediates
+#pragma unroll
+            for (int j = 0; j < kMaxTiles; ++j) arow[j] = abase[j] + kh * rowb;
+#pragma unroll
+            for (int q = 0; q < C::STEPS_ROW; ++q) {
+                const int s = kh * C::STEPS_ROW + q;
+#pragma unroll
+                for (int j = 0; j < kMaxTiles; ++j) {
+                    if (wm_ + 4 * j >= ntiles) continue;  // wave-uniform
+                    if constexpr (sizeof(T) == 4) {
+                        const float a = *reinterpret_cast<const float *>(patch + arow[j] + q * C::KPS * ES);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s], acc[j], 0, 0, 0);
+                    } else {
+                        const i32x4 a = *reinterpret_cast<const i32x4 *>(patch + arow[j] + q * C::KPS * ES);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bw[s]), acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue: affine, ReLU, max into the pooled rows.  y >= 0 everywhere, so a stem row
+        // that does not exist (above the image for the first pair, below it for the last) counts
+        // as 0, the value the pooled rows start from.  Four adjacent columns 4c .. 4c+3 feed the
+        // windows 2c (4c, 4c+1), 2c+1 (4c+1 .. 4c+3) and 2c+2 (4c+3): three LDS maxima.
+        auto finish = [&](float a) -> unsigned {
+            float v = fmaf(a, sc, sh);
+            if (p.relu) v = v > 0.f ? v : 0.f;  // never -0.0: the bit pattern must order like the value
+            if constexpr (sizeof(T) == 2) v = (float)(bf16_t)v;
+            return __float_as_uint(v);
+        };
+        auto put = [&](int pl, int pw, const unsigned (&v)[4]) {
+            if (ph0 + pl >= p.PH) return;
+            unsigned *q0 = reinterpret_cast<unsigned *>(pooled) + ((pl * p.PW + pw) * kCout + n);
+            atomicMax(q0, max(v[0], v[1]));
+            atomicMax(q0 + kCout, max(max(v[1], v[2]), v[3]));
+            if (pw + 2 < p.PW) atomicMax(q0 + 2 * kCout, v[3]);
+        };
+#pragma unroll
+        for (int j = 0; j < kMaxTiles; ++j) {
+            const int tile = wm_ + 4 * j;
+            if (tile >= ntiles) continue;
+            if (tile < n2d) {
+                const int pw = 4 * tile + 2 * lh_;  // (8*tile + 4*lh) / 2
+                unsigned y[4][4];
+#pragma unroll
+                for (int dr = 0; dr < 4; ++dr) {
+                    const int oh = oh_first + dr;
+                    const bool real = oh >= 0 && oh < p.Ho;  // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[dr][i] = real ? finish(acc[j][4 * dr + i]) : 0u;
+                }
+                unsigned v0[4], v1[4];  // windows of pooled row 0: stem rows 0..2; of row 1: 2..4
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v0[i] = max(max(y[0][i], y[1][i]), y[2][i]);
+                    v1[i] = max(y[2][i], y[3][i]);
+                }
+                put(0, pw, v0);
+                put(1, pw, v1);
+            } else {
+                const int oh = oh_first + 4;
+                if (oh >= p.Ho) continue;  // wave-uniform
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ox = 32 * (tile - n2d) + 8 * g + 4 * lh_;
+                    if (ox >= p.Wo) continue;
+                    unsigned v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = finish(acc[j][4 * g + i]);
+                    put(1, ox >> 1, v);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- pooled rows -> global, then clear them for the next item
+        {
+            const int rows = min(2, p.PH - ph0);
+            const int nout = rows * p.PW * kCout;
+            char *obase = static_cast<char *>(p.out) + ((size_t)b * p.PH + ph0) * p.PW * kCout * ES;
+            for (int i = t * 4; i < nout; i += 512 * 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(pooled + i);
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4 *>(obase + (size_t)i * 4) = v;
+                } else {
+                    typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 o;
+                    o[0] = (bf16_t)v.x, o[1] = (bf16_t)v.y, o[2] = (bf16_t)v.z, o[3] = (bf16_t)v.w;
+                    *reinterpret_cast<bf16x4 *>(obase + (size_t)i * 2) = o;
+                }
+                *reinterpret_cast<float4 *>(pooled + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// OIHW fp32 [64][3][7][7] -> the panel the kernel keeps in registers
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float *__restrict__ w, T *__restrict__ packed,
+                                                        int Cin)
+{
+    using C = Cfg<T>;
+    const int total = kCout * kK * C::KROW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int tpos = i % C::KROW, kh = (i / C::KROW) % kK, oc = i / (C::KROW * kK);
+        int kw, c;
+        if (sizeof(T) == 4) {
+            kw = tpos / 3;
+            c = tpos % 3;
+            if (tpos >= 21) kw = kK;  // the pad slot
+        } else {
+            kw = 2 * (tpos >> 3) + ((tpos >> 2) & 1);
+            c = tpos & 3;
+        }
+        const float v = (kw < kK && c < Cin) ? w[((oc * Cin + c) * kK + kh) * kK + kw] : 0.f;
+        packed[i] = (T)v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+uint64_t rn_stem_pool_packed_weight_numel(int dtype)
+{
+    return (uint64_t)kCout * kK * (dtype == RN_DTYPE_BF16 ? Cfg<bf16_t>::KROW : Cfg<float>::KROW);
+}
+
+int rn_stem_pool_pack_weight_dt(rn_ctx *ctx, int dtype, const float *weight_oihw, void *packed,
+                                uint64_t in_channels)
+{
+    RN_ENTER(ctx);
+    RN_REQUIRE(ctx, weight_oihw && packed, "null tensor");
+    RN_REQUIRE(ctx, in_channels >= 1 && in_channels <= 3, "the fused stem takes 1..3 input channels");
+    if (dtype == RN_DTYPE_BF16)
+        stem_pack_kernel<bf16_t><<<16, 256, 0, ctx->stream>>>(weight_oihw, (bf16_t *)packed, (int)in_channels);
+    else if (dtype == RN_DTYPE_F32)
+        stem_pack_kernel<float><<<16, 256, 0, ctx->stream>>>(weight_oihw, (float *)packed, (int)in_channels);
+    else
+        return rn_set_error(ctx, RN_ERR_INVALID, "rn_stem_pool_pack_weight_dt: unknown dtype");
+    return rn_after_launch(ctx, "rn_stem_pool_pack_weight_dt");
+}
+
+int rn_stem_pool_forward_dt(rn_ctx *ctx, int dtype, const void *inp_padded, void *out,
+                            const void *packed_weight, const float *scale, const float *shift,
+                            int relu, uint64_t B, uint64_t Hp, uint64_t Wp)
+{
+    RN_ENTER(ctx);
+    if (B == 0) return RN_OK;
+    RN_REQUIRE(ctx, dtype == RN_DTYPE_F32 || dtype == RN_DTYPE_BF16, "unknown dtype");
+    RN_REQUIRE(ctx, inp_padded && out && packed_weight && inp_padded != out, "null or aliased tensor");
+    RN_REQUIRE(ctx, Hp >= 7 && Wp >= 7 && Hp < (1u << 14) && Wp < (1u << 14), "image size out of range");
+    const uint64_t Ho = rn_conv_output_size(Hp, 7, 2, 0), Wo = rn_conv_output_size(Wp, 7, 2, 0);
+    const uint64_t PH = rn_conv_output_size(Ho, 3, 2, 1), PW = rn_conv_output_size(Wo, 3, 2, 1);
+    RN_REQUIRE(ctx, Wo / 8 + (Wo + 31) / 32 <= 4 * kMaxTiles, "image too wide for the fused stem (conv output width <= 128)");
+    RN_REQUIRE(ctx, Wo % 8 == 0, "the fused stem needs a conv output width that is a multiple of 8");
+    const int es = dtype == RN_DTYPE_BF16 ? 2 : 4, cs = dtype == RN_DTYPE_BF16 ? 4 : 3;
+    RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(inp_padded) | reinterpret_cast<uintptr_t>(out) |
+                      reinterpret_cast<uintptr_t>(packed_weight)) & 15) == 0,
+               "tensors must be 16-byte aligned");
+    // the patch copy moves 16-byte (bf16) / 8-byte (fp32) granules of whole image rows
+    RN_REQUIRE(ctx, (Wp * cs * es) % (dtype == RN_DTYPE_BF16 ? 16 : 8) == 0,
+               "padded image width must make rows a multiple of 16 bytes (bf16) / 8 bytes (fp32)");
+    RN_REQUIRE(ctx, B * Hp * Wp * cs < (1ull << 40) && B * PH * PW < (1ull << 31), "tensor too large");
+    StemParams p;
+    p.in = inp_padded;
+    p.w = packed_weight;
+    p.scale = scale;
+    p.shift = shift;
+    p.out = out;
+    p.B = (int)B;
+    p.Hp = (int)Hp;
+    p.Wp = (int)Wp;
+    p.Ho = (int)Ho;
+    p.Wo = (int)Wo;
+    p.PH = (int)PH;
+    p.PW = (int)PW;
+    p.relu = relu;
+    p.pairs = (int)rn_ceil_div(PH, 2);
+    p.items = (unsigned)(B * (uint64_t)p.pairs);
+    const size_t patch = 48 + (((size_t)kPatchRows * Wp * cs * es + 15) & ~(size_t)15);
+    RN_REQUIRE(ctx, patch <= 48 * 1024, "image too wide for the fused stem (patch)");
+    const size_t lds_bytes = patch + (size_t)2 * PW * kCout * sizeof(float);
+    RN_REQUIRE(ctx, lds_bytes <= 160 * 1024, "image too wide for the fused stem (LDS)");
+    const int per_cu = lds_bytes <= 80 * 1024 ? 2 : 1;
+    unsigned grid = 256u * (unsigned)per_cu;
+    if (grid > p.items) grid = p.items;
+    // more than 64 KB of dynamic LDS has to be allowed once per kernel and device (not a stream
+    // operation: done on the first call, which a capturing caller makes eagerly anyway)
+    int *allowed = &ctx->occupancy[250 + (dtype == RN_DTYPE_BF16 ? 1 : 0)];
+    if (lds_bytes > 64 * 1024 && *allowed < (int)lds_bytes) {
+        RN_HIP_TRY(ctx, hipFuncSetAttribute(dtype == RN_DTYPE_BF16 ? (const void *)stem_pool_kernel<bf16_t>
+                                                                   : (const void *)stem_pool_kernel<float>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        *allowed = 160 * 1024;
+    }
+    if (dtype == RN_DTYPE_BF16)
+        stem_pool_kernel<bf16_t><<<grid, 512, lds_bytes, ctx->stream>>>(p);
+    else
+        stem_pool_kernel<float><<<grid, 512, lds_bytes, ctx->stream>>>(p);
+    return rn_after_launch(ctx, "rn_stem_pool_forward_dt");
+}
+
+}  // extern "C"

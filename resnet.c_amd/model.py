@@ -270,6 +270,13 @@ class NativeModel:
         """2 (default): batches of >= 128 images run as two halves on two streams; 1: one stream."""
         L.check(L.lib().rn_model_set_streams(self.handle, int(streams)), "rn_model_set_streams")
 
+    def streams(self) -> int:
+        return int(L.lib().rn_model_get_streams(self.handle))
+
+    def set_stem_pool_fusion(self, on: bool) -> None:
+        """Fused mode: conv1 + bn1 + relu + maxpool as one launch (default on)."""
+        L.check(L.lib().rn_model_set_stem_pool_fusion(self.handle, int(on)), "rn_model_set_stem_pool_fusion")
+
     def set_front_parts(self, parts: int) -> None:
         """Stem, max-pool and first stage in `parts` slices of the batch (Infinity-Cache reuse)."""
         L.check(L.lib().rn_model_set_front_parts(self.handle, int(parts)), "rn_model_set_front_parts")

@@ -319,6 +319,36 @@ def test_streams_and_depth_first_front_change_speed_not_results(state50, finch, 
         m.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_stem_pool_changes_launches_not_results(state50, finch, golden_dir, dtype):
+    """conv1 + bn1 + relu + maxpool as one launch (default) against the two-launch form: one op
+    fewer, the same logits up to the stem's summation order, same top-1, golden logits held."""
+    m = R.NativeModel("resnet50", state=state50, dtype=dtype)
+    try:
+        x = np.concatenate([finch, R.weights.generate_input(5, seed=83)])
+        m.set_profiling(True)
+        fused = m.forward(x, fused=True)
+        n_fused = [r["op"] for r in m.profile()]
+        m.set_stem_pool_fusion(False)
+        plain = m.forward(x, fused=True)
+        n_plain = [r["op"] for r in m.profile()]
+        m.set_profiling(False)
+        assert len(n_plain) == len(n_fused) + 1
+        assert "conv2d+epilogue+maxpool" in n_fused and "maxpool2d" not in n_fused
+        assert "maxpool2d" in n_plain
+        tol = 2e-5 if dtype == "f32" else 0.08
+        assert np.abs(fused - plain).max() <= tol
+        assert np.array_equal(fused.argmax(1), plain.argmax(1))
+        if dtype == "f32":
+            want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
+            assert np.abs(fused[:1] - want).max() <= TOL
+        # batch invariance holds for the fused launch too
+        m.set_stem_pool_fusion(True)
+        assert np.array_equal(m.forward(x[2:3], fused=True), fused[2:3])
+    finally:
+        m.close()
+
+
 def test_sharded_model_equals_whole_batch(state50, model50, finch):
     """rn_shard_*: one host thread + context + model per listed device, contiguous batch split,
     logits concatenated on the host (main.cu:228-254 over several devices).  A

@@ -563,3 +563,41 @@ def test_one_thread_two_contexts_interleaved():
             L.check(lib.rn_free(c.handle, p), "free", c.handle)
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 32, 32), (1, 3, 40, 48), (2, 2, 26, 16)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_fused_stem_and_maxpool_match_the_four_reference_ops(shape, bf16):
+    """rn_stem_pool_forward_dt: conv 7x7/2 + batch-norm (folded) + ReLU + max-pool 3x3/2/1 as one
+    launch (main.cu:179-192) against the oracle's four ops.  Odd row counts, the first pooled row
+    (whose top window row does not exist), windows over the right and bottom edges, fewer than
+    three input channels; bf16: oracle on bf16-rounded operands, stem output rounded to bf16
+    before the pool as the unfused path does."""
+    B, Cin, H, W = shape
+    seed = 1200 + sum(shape)
+    x, w = rnd(shape, seed), rnd((64, Cin, 7, 7), seed + 1) / np.sqrt(Cin * 49)
+    g = np.random.default_rng(seed + 2)
+    sc, sh = g.random(64, dtype=np.float32) + 0.5, g.standard_normal(64, dtype=np.float32) * 0.3
+    if bf16:
+        x, w = ops.bf16_round(x), ops.bf16_round(w)
+    y = O.conv2d(x, w, 2, 3)
+    y = O.relu_(y * sc[None, :, None, None] + sh[None, :, None, None])
+    if bf16:
+        y = ops.bf16_round(y)
+    want = O.maxpool2d(y, 3, 2, 1)
+    got = ops.stem_pool(x, w, sc, sh, True, bf16=bf16)
+    assert got.shape == want.shape
+    tol = (2 ** -7 if bf16 else 2e-6 * np.sqrt(Cin * 49)) * float(np.abs(want).max()) + 1e-6
+    assert np.abs(got - want).max() <= tol
+    assert (got >= 0).all() and np.array_equal(got, ops.stem_pool(x, w, sc, sh, True, bf16=bf16))
+    # against the engine's own unfused kernels: same products, another summation order
+    if not bf16 and Cin == 3:
+        conv = ops.conv2d_nhwc_fused(x, w, 2, 3, sc, sh, None, True)
+        assert np.abs(got - ops.maxpool2d(conv, 3, 2, 1, "nhwc")).max() <= tol
+
+
+def test_fused_stem_refuses_what_it_cannot_do():
+    from resnet_c_amd import _lib as L
+    x, w = rnd((1, 3, 30, 30), 5), rnd((64, 3, 7, 7), 6)
+    with pytest.raises(L.RnError):      # conv output width 15: not a multiple of 8
+        ops.stem_pool(x, w)

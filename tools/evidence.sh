@@ -9,6 +9,7 @@ export TMPDIR=/tmp
 if [ $what = bench ] || [ $what = all ]; then
   python bench.py > $o/bench_f32.json 2> $o/bench_f32.err
   python bench.py --dtype bf16 --no-cpu-baseline --no-pipeline > $o/bench_bf16.json 2> $o/bench_bf16.err
+  python bench.py --dtype bf16 --streams 1 --no-cpu-baseline --no-pipeline > $o/bench_bf16_one_stream.json 2> $o/bench_bf16_1s.err
   python bench.py --arch resnet152 --batch 128 --no-cpu-baseline --no-pipeline > $o/bench_resnet152_b128.json 2> $o/bench_resnet152.err
   python bench.py --mode ops --no-cpu-baseline --no-pipeline > $o/bench_ops_mode.json 2> $o/bench_ops.err
   python tools/layer_report.py --tune > $o/layers_f32.txt 2>&1
@@ -17,12 +18,14 @@ if [ $what = bench ] || [ $what = all ]; then
 fi
 if [ $what = trace ] || [ $what = all ]; then
   for dt in f32 bf16; do
-    rocprofv3 --kernel-trace --stats --output-format csv -d $o/trace_$dt -- python3 bench.py --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline --no-pipeline > $o/bench_under_rocprof_$dt.json 2> $o/trace_$dt.err
+    # one stream: with the batch as two parts on two streams the kernels of the parts overlap and a
+    # kernel's duration in the trace is no longer its own
+    rocprofv3 --kernel-trace --stats --output-format csv -d $o/trace_$dt -- python3 bench.py --dtype $dt --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --no-pipeline > $o/bench_under_rocprof_$dt.json 2> $o/trace_$dt.err
     python tools/ktrace_summary.py $o/trace_$dt 13 $o/timed_region_kernels_$dt.json > /dev/null
     f=$(find $o/trace_$dt -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $o/kernel_stats_$dt.csv
     find $o/trace_$dt -name '*kernel_trace.csv' -size +8M -delete
   done
-  rocprofv3 --kernel-trace --stats --output-format csv -d $o/trace_ops -- python3 bench.py --mode ops --steps 10 --warmup 3 --no-cpu-baseline --no-pipeline > $o/bench_under_rocprof_ops.json 2> $o/trace_ops.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $o/trace_ops -- python3 bench.py --mode ops --streams 1 --steps 10 --warmup 3 --no-cpu-baseline --no-pipeline > $o/bench_under_rocprof_ops.json 2> $o/trace_ops.err
   python tools/ktrace_summary.py $o/trace_ops 13 $o/timed_region_kernels_ops_mode.json > /dev/null
   f=$(find $o/trace_ops -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $o/kernel_stats_ops_mode.csv
   find $o/trace_ops -name '*kernel_trace.csv' -size +8M -delete
@@ -30,7 +33,7 @@ fi
 if [ $what = pmc ] || [ $what = all ]; then
   for dt in f32 bf16; do
     for c in FETCH_SIZE WRITE_SIZE; do
-      rocprofv3 --pmc $c --output-format csv -d $o/pmc_${dt}_$c -- python3 bench.py --dtype $dt --steps 2 --warmup 1 --profile-forwards 1 --no-cpu-baseline --no-pipeline > /dev/null 2> $o/pmc_${dt}_$c.err
+      rocprofv3 --pmc $c --output-format csv -d $o/pmc_${dt}_$c -- python3 bench.py --dtype $dt --streams 1 --steps 2 --warmup 1 --profile-forwards 1 --no-cpu-baseline --no-pipeline > /dev/null 2> $o/pmc_${dt}_$c.err
     done
   done
   python tools/pmc_traffic.py $o/pmc_f32_FETCH_SIZE $o/pmc_f32_WRITE_SIZE $o/hbm_traffic_pmc_f32.json 72 24.97e9 "ResNet-50 fp32 B=256 fused; separate --pmc passes; FETCH_SIZE x2" > /dev/null
