@@ -4,6 +4,7 @@
 #   tools/evidence.sh [bench|trace|pmc|all]
 what=${1:-all}
 o=gpurun_out/ev
+rm -rf $o
 mkdir -p $o
 export TMPDIR=/tmp
 if [ $what = bench ] || [ $what = all ]; then

@@ -16,13 +16,17 @@ def family(name):
         return "conv_gemm_kernel"
     if "conv_wide_kernel" in name:
         return "conv_wide_kernel"
+    if "stem_pool_kernel" in name:
+        return "stem_pool_kernel"
+    if "maxpool3_nhwc_kernel" in name:
+        return "maxpool3_nhwc_kernel"
     n = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return n.split("(")[0].split("<")[0]
 
 
 def main():
     d, F = sys.argv[1], int(sys.argv[2])
-    f = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
     rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"])
                    for r in csv.DictReader(open(f))), key=lambda r: r[0])
     starts = [i for i, r in enumerate(rows) if "nchw_to_nhwc" in r[2]]
@@ -39,7 +43,8 @@ def main():
                            "ms_per_forward": v[1] / F / 1e6} for k, v in sorted(fam.items())}}
     # the contraction family as bench.py's `roofline` counts it: the implicit-GEMM launches plus
     # the launches that add the K-chunk pieces of cut tail tiles
-    con = [v for k, v in fam.items() if k in ("conv_gemm_kernel", "conv_wide_kernel", "splitk_finish_kernel")]
+    con = [v for k, v in fam.items()
+           if k in ("conv_gemm_kernel", "conv_wide_kernel", "splitk_finish_kernel", "stem_pool_kernel")]
     if con:
         n, ns = sum(v[0] for v in con), sum(v[1] for v in con)
         out["contraction_family"] = {"launches_per_forward": n / F, "avg_us": ns / n / 1e3,
