@@ -976,7 +976,7 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     // Chunked K sum: a property of the LAYER (element type, kind, K), never of the batch size or
     // the tile, so that every launch of the layer adds the same products in the same order.
     const bool chunked = dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32 && !second && !exact &&
-                         p.nk >= 32 && Cout % 4 == 0;
+                         p.nk >= 32 && Cout % 4 == 0;  // (nk >= 16 measured: -0.3 % on the fp32 step)
     if (chunked && BMsel == 128 && BNsel == 128) BNsel = 64;
     const uint64_t tiles_n = rn_ceil_div(Cout, BNsel);
     const uint64_t tiles_m = rn_ceil_div((uint64_t)p.M, BMsel);
