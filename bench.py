@@ -97,8 +97,11 @@ def max_over_ranks(value: float, world: int, device=None) -> float:
     return float(t.item())
 
 
-def cpu_baseline(arch: str, state, seconds_budget: float = 15.0):
-    """Reference-equivalent PyTorch forward on the host CPU, bounded sample."""
+def cpu_baseline(arch: str, state, seconds_budget: float = 15.0, engine=None):
+    """Reference-equivalent PyTorch forward on the host CPU, bounded sample.  `engine`: a callable
+    (NCHW fp32 array -> logits) of the GPU path; the port's logits on the sample's first images
+    are held against it in this very run (the port itself is pinned to the reference module's
+    golden logits by tests/test_oracle.py)."""
     import numpy as np
     import torch
 
@@ -122,7 +125,12 @@ def cpu_baseline(arch: str, state, seconds_budget: float = 15.0):
         y = TP.resnet_forward(t, x, arch)
     dt = time.perf_counter() - t0
     assert np.isfinite(y.numpy()).all()
+    check = None
+    if engine is not None:
+        got = engine(x[:4].numpy())
+        check = float(np.abs(got - y[:4].numpy()).max())
     return {"value": round(B * reps / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "max_abs_diff_vs_gpu_logits_on_4_images": check,
             "sample": f"{reps} forwards of batch {B} ({arch} fp32, torch {torch.__version__} "
                       f"functional port of pytorch_inference.py, {threads} threads of "
                       f"{os.cpu_count()} host cpus)"}
@@ -377,7 +385,10 @@ def main():
     if world == 1 and not args.no_pipeline:
         result["host_pipeline"] = host_pipeline(model, x_host, B, fused, args.steps)
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.arch, state)
+        result["cpu_baseline"] = cpu_baseline(args.arch, state,
+                                              engine=lambda a: model.forward(a, fused=fused))
+        diff = result["cpu_baseline"]["max_abs_diff_vs_gpu_logits_on_4_images"]
+        assert diff is not None and diff <= (1e-4 if args.dtype == "f32" else 0.25), diff
     print(json.dumps(result))
 
 
