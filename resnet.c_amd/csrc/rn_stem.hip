@@ -27,7 +27,11 @@
 //    has one; padded taps are skipped, ops.cu:65-67);
 //  * the pooled rows leave as whole 128..256-byte pixels.  The stem tensor is never written.
 //
-// Bound: matrix pipe in fp32 (0.50 ms at peak for B=256 with the halo), HBM in bf16 (0.3 GB).
+// Bound: matrix pipe in fp32 (0.52 ms at peak for B=256 with the halo), HBM in bf16 (0.3 GB).
+// Measured at B=256 (timing-only builds with parts switched off): fp32 0.68 ms = 0.57 matrix
+// phase + 0.09 epilogue arithmetic (of which 0.01 the LDS maxima) + 0.02 the rest; bf16 0.22 ms =
+// 0.11 + 0.09 + 0.02: the register epilogue (80 values per lane: affine, ReLU, rounding, maxima)
+// is what a second resident block would hide, and 242 VGPRs allow only one.
 #include <type_traits>
 
 #include "rn_conv_params.h"
@@ -81,9 +85,11 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
     constexpr int STEPS = kK * C::STEPS_ROW;    // MFMA k-steps: 77 / 14
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int rowb = p.Wp * PIXB;               // bytes per patch row
+    // LDS: two input patches and two pooled-row buffers (item i is multiplied out of one patch
+    // while the next item's lands in the other and the previous item's pooled rows leave)
     const int patch_bytes = 48 + ((kPatchRows * rowb + 15) & ~15);  // slack: shifted base in front, piece overhang behind
-    float *const pooled = reinterpret_cast<float *>(lds + patch_bytes);  // [2][PW][64]
-    const int pooled_n = 2 * p.PW * kCout;
+    const int pooled_n = 2 * p.PW * kCout;                           // floats of one [2][PW][64] buffer
+    float *const pooled0 = reinterpret_cast<float *>(lds + 2 * patch_bytes);
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
     const float sc = p.scale ? p.scale[n] : 1.f;
     const float sh = p.shift ? p.shift[n] : 0.f;
 
-    for (int i = t; i < pooled_n; i += 512) pooled[i] = 0.f;
+    for (int i = t; i < 2 * pooled_n; i += 512) pooled0[i] = 0.f;
 
     // The input patch of an item: rows [row0, row0 + 15) of the padded image clipped to the image --
     // one contiguous block of memory -- fetched as 16-byte pieces from the 16-byte boundary below
@@ -140,26 +146,56 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
             stage[k] = *reinterpret_cast<const i32x4 *>(src + (o < nbytes ? o : 0));
         }
     };
-    auto patch_store = [&](unsigned item) -> int {
+    auto patch_store = [&](unsigned item, int buf) -> int {
         const char *src;
         int dst_off, nbytes, base;
         patch_src(item, src, dst_off, nbytes, base);
 #pragma unroll
         for (int k = 0; k < kPieces; ++k) {
             const int o = (k * 512 + t) * 16;
-            if (o < nbytes) *reinterpret_cast<i32x4 *>(lds + dst_off + o) = stage[k];
+            if (o < nbytes) *reinterpret_cast<i32x4 *>(lds + buf * patch_bytes + dst_off + o) = stage[k];
         }
-        return base;
+        return buf * patch_bytes + base;
+    };
+    // pooled rows of a finished item -> global, then cleared for the item after next
+    auto pooled_out = [&](unsigned item, float *pooled) {
+        const int b = (int)(item / (unsigned)p.pairs), ph0 = 2 * (int)(item % (unsigned)p.pairs);
+        const int rows = min(2, p.PH - ph0);
+        const int nout = rows * p.PW * kCout;
+        char *obase = static_cast<char *>(p.out) + ((size_t)b * p.PH + ph0) * p.PW * kCout * ES;
+        for (int i = t * 4; i < nout; i += 512 * 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(pooled + i);
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<float4 *>(obase + (size_t)i * 4) = v;
+            } else {
+                typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 o;
+                o[0] = (bf16_t)v.x, o[1] = (bf16_t)v.y, o[2] = (bf16_t)v.z, o[3] = (bf16_t)v.w;
+                *reinterpret_cast<bf16x4 *>(obase + (size_t)i * 2) = o;
+            }
+            *reinterpret_cast<float4 *>(pooled + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
 
-    if (blockIdx.x < p.items) patch_fetch(blockIdx.x);
-    for (unsigned item = blockIdx.x; item < p.items; item += gridDim.x) {
-        const int b = (int)(item / (unsigned)p.pairs), pj = (int)(item % (unsigned)p.pairs);
+    // Software pipeline over the block's items, ONE barrier per item: while item i is multiplied
+    // out of patch[i&1], the patch of item i+1 is written to the other buffer (fetched to
+    // registers during item i-1), the fetch of item i+2 is issued, and the pooled rows of item
+    // i-1 leave from pooled[(i-1)&1].  All of that sits in the middle of item i's k loop, between
+    // MFMAs; only the epilogue of an item is not covered by matrix work.
+    const unsigned step = gridDim.x;
+    if (blockIdx.x >= p.items) return;
+    patch_fetch(blockIdx.x);
+    int patch_off = patch_store(blockIdx.x, 0);
+    if (blockIdx.x + step < p.items) patch_fetch(blockIdx.x + step);
+    __syncthreads();
+    int cur = 0;
+    for (unsigned item = blockIdx.x; item < p.items; item += step, cur ^= 1) {
+        const int pj = (int)(item % (unsigned)p.pairs);
         const int ph0 = 2 * pj;
         const int oh_first = 2 * ph0 - 1;     // stem row of r = 0 (-1 for the first pair: no such row)
-        const char *const patch = lds + patch_store(item);  // patch row 0
-        __syncthreads();
-        if (item + gridDim.x < p.items) patch_fetch(item + gridDim.x);
+        const char *const patch = lds + patch_off;  // patch row 0 of this item
+        float *const pooled = pooled0 + cur * pooled_n;
+        int next_off = 0;
 
         // Per-item copies of the lane / wave coordinates that the compiler cannot see through:
         // everything below depends only on them and on the kernel arguments, and hoisted out of
@@ -186,28 +222,45 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
             // patch row 2r + kh, pixel 2*ox + kw; the lane half takes the upper half of a k-step
             abase[j] = ox < p.Wo ? 2 * r * rowb + 2 * ox * PIXB + lh_ * (C::KPS / 2) * ES : 0;
         }
+        // NT = tiles this wave multiplies (a compile-time count: a per-tile "does it exist" test
+        // inside the k loop puts a branch around every MFMA and serialises read -> wait -> MFMA)
+        auto contract = [&](auto nt_c) {
+            constexpr int NT = decltype(nt_c)::value;
 #pragma unroll
-        for (int kh = 0; kh < kK; ++kh) {
-            int arow[kMaxTiles];  // this kernel row's fragment base; the k-steps are immediates
+            for (int kh = 0; kh < kK; ++kh) {
+                if (kh == 3) {  // the other buffers' turn (see above); their last users are a barrier behind
+                    if (item + step < p.items) {
+                        next_off = patch_store(item + step, cur ^ 1);
+                        if (item + 2 * step < p.items) patch_fetch(item + 2 * step);
+                    }
+                    if (item != blockIdx.x) pooled_out(item - step, pooled0 + (cur ^ 1) * pooled_n);
+                }
+                int arow[NT];  // this kernel row's fragment base; the k-steps are immediates
 #pragma unroll
-            for (int j = 0; j < kMaxTiles; ++j) arow[j] = abase[j] + kh * rowb;
+                for (int j = 0; j < NT; ++j) arow[j] = abase[j] + kh * rowb;
 #pragma unroll
-            for (int q = 0; q < C::STEPS_ROW; ++q) {
-                const int s = kh * C::STEPS_ROW + q;
+                for (int q = 0; q < C::STEPS_ROW; ++q) {
+                    const int s = kh * C::STEPS_ROW + q;
 #pragma unroll
-                for (int j = 0; j < kMaxTiles; ++j) {
-                    if (wm_ + 4 * j >= ntiles) continue;  // wave-uniform
-                    if constexpr (sizeof(T) == 4) {
-                        const float a = *reinterpret_cast<const float *>(patch + arow[j] + q * C::KPS * ES);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s], acc[j], 0, 0, 0);
-                    } else {
-                        const i32x4 a = *reinterpret_cast<const i32x4 *>(patch + arow[j] + q * C::KPS * ES);
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bw[s]), acc[j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) {
+                        if constexpr (sizeof(T) == 4) {
+                            const float a = *reinterpret_cast<const float *>(patch + arow[j] + q * C::KPS * ES);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s], acc[j], 0, 0, 0);
+                        } else {
+                            const i32x4 a = *reinterpret_cast<const i32x4 *>(patch + arow[j] + q * C::KPS * ES);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bw[s]), acc[j], 0, 0, 0);
+                        }
                     }
                 }
             }
-        }
+        };
+        // tiles wm, wm+4, ... < ntiles: five for the widest images' first wave rows, else four or
+        // fewer (a tile that does not exist is multiplied on patch garbage and never looked at)
+        if (wm_ + 4 * (kMaxTiles - 1) < ntiles)
+            contract(std::integral_constant<int, kMaxTiles>{});
+        else
+            contract(std::integral_constant<int, kMaxTiles - 1>{});
 
         // ---- epilogue: affine, ReLU, max into the pooled rows.  y >= 0 everywhere, so a stem row
         // that does not exist (above the image for the first pair, below it for the last) counts
@@ -263,26 +316,12 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
             }
         }
         __syncthreads();
-
-        // ---- pooled rows -> global, then clear them for the next item
-        {
-            const int rows = min(2, p.PH - ph0);
-            const int nout = rows * p.PW * kCout;
-            char *obase = static_cast<char *>(p.out) + ((size_t)b * p.PH + ph0) * p.PW * kCout * ES;
-            for (int i = t * 4; i < nout; i += 512 * 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(pooled + i);
-                if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<float4 *>(obase + (size_t)i * 4) = v;
-                } else {
-                    typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
-                    bf16x4 o;
-                    o[0] = (bf16_t)v.x, o[1] = (bf16_t)v.y, o[2] = (bf16_t)v.z, o[3] = (bf16_t)v.w;
-                    *reinterpret_cast<bf16x4 *>(obase + (size_t)i * 2) = o;
-                }
-                *reinterpret_cast<float4 *>(pooled + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        __syncthreads();
+        patch_off = next_off;
+    }
+    // the last item's pooled rows (cur was flipped once more by the loop)
+    {
+        const unsigned n_mine = (p.items - 1 - blockIdx.x) / step;  // index of this block's last item
+        pooled_out(blockIdx.x + n_mine * step, pooled0 + (cur ^ 1) * pooled_n);
     }
 }
 
@@ -372,10 +411,9 @@ int rn_stem_pool_forward_dt(rn_ctx *ctx, int dtype, const void *inp_padded, void
     p.items = (unsigned)(B * (uint64_t)p.pairs);
     const size_t patch = 48 + (((size_t)kPatchRows * Wp * cs * es + 15) & ~(size_t)15);
     RN_REQUIRE(ctx, patch <= 48 * 1024, "image too wide for the fused stem (patch)");
-    const size_t lds_bytes = patch + (size_t)2 * PW * kCout * sizeof(float);
+    const size_t lds_bytes = 2 * patch + (size_t)2 * 2 * PW * kCout * sizeof(float);
     RN_REQUIRE(ctx, lds_bytes <= 160 * 1024, "image too wide for the fused stem (LDS)");
-    const int per_cu = lds_bytes <= 80 * 1024 ? 2 : 1;
-    unsigned grid = 256u * (unsigned)per_cu;
+    unsigned grid = 256u;  // one block per CU (registers): persistent, items grid-stride
     if (grid > p.items) grid = p.items;
     // more than 64 KB of dynamic LDS has to be allowed once per kernel and device (not a stream
     // operation: done on the first call, which a capturing caller makes eagerly anyway)
