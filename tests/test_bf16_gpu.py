@@ -2,6 +2,7 @@
 the oracle for these kernels is the same CPU restatement run on bf16-rounded operands:
 products of bf16 values are exact in fp32, so the only differences are fp32 summation
 order and the final rounding of the output to bf16 (rel. 2^-9)."""
+import ctypes
 import os
 
 import numpy as np
@@ -98,6 +99,80 @@ def test_bf16_conv_pair_every_tile_candidate():
             lib.rn_ctx_set_conv_tile(ctx.handle, cand)
             got = ops.conv2d_nhwc_pair(t, w, x2, w2, 1, 0, s2, sc1, sc2, shift, None, True, bf16=True)
             assert np.array_equal(got, base), cand
+    finally:
+        lib.rn_ctx_set_conv_tile(ctx.handle, 0)
+
+
+def test_wide_kernel_race_screen_at_full_size():
+    """The LDS-DMA ring is ordered by counted vmcnt waits and one barrier per K step.  A read
+    that slipped ahead of its DMA would show as rare wrong tiles that come and go with timing, so
+    this runs the real layer shapes (B=256: 196 blocks of 256x256 on layer3's 3x3, 196 of 256x128
+    on layer4's) many times under load on device-resident buffers and holds every run to the
+    4-wave kernel's bits."""
+    from resnet_c_amd import _lib as L
+    from resnet_c_amd.tensor import _DeviceBuffer
+    ctx, lib = R.get_ctx(), L.lib()
+    for (B, H, W, Cin, Cout, k, pad, cands) in [(256, 14, 14, 256, 256, 3, 1, (9, 10, 11)),
+                                                (256, 7, 7, 512, 512, 3, 1, (9, 10, 11)),
+                                                (64, 28, 28, 128, 128, 3, 1, (10, 12)),
+                                                (256, 14, 14, 1024, 256, 1, 0, (9,))]:
+        g = np.random.default_rng(B + Cin + k)
+        n_in, n_w, n_out = B * H * W * Cin, Cout * k * k * Cin, B * H * W * Cout
+        x = _DeviceBuffer(ctx, n_in * 2)
+        w = _DeviceBuffer(ctx, n_w * 2)
+        xh = ops.to_bf16_bits(g.standard_normal(n_in, dtype=np.float32))
+        wh = ops.to_bf16_bits(g.standard_normal(n_w, dtype=np.float32) / np.sqrt(Cin * k * k))
+        L.check(lib.rn_memcpy_h2d(ctx.handle, x.ptr, xh.ctypes.data, xh.nbytes), "h2d", ctx.handle)
+        L.check(lib.rn_memcpy_h2d(ctx.handle, w.ptr, wh.ctypes.data, wh.nbytes), "h2d", ctx.handle)
+        out = _DeviceBuffer(ctx, n_out * 2)
+        ep = L.Epilogue(None, None, None, 1)
+
+        def run(cand):
+            lib.rn_ctx_set_conv_tile(ctx.handle, cand)
+            L.check(lib.rn_conv2d_nhwc_forward_dt(ctx.handle, L.RN_DTYPE_BF16, L.RN_DTYPE_BF16, x.ptr, out.ptr, w.ptr,
+                                                  k, 1, pad, H, W, B, Cin, Cout, H, W, ctypes.byref(ep)), "conv", ctx.handle)
+
+        def fetch():
+            ctx.sync()
+            h = np.empty(n_out, dtype=np.uint16)
+            L.check(lib.rn_memcpy_d2h(ctx.handle, h.ctypes.data, out.ptr, h.nbytes), "d2h", ctx.handle)
+            return h
+
+        try:
+            run(5)
+            want = fetch()
+            assert want.any()
+            for cand in cands:
+                for rep in range(12):
+                    for _ in range(6):      # back-to-back launches: the chip is warm and loaded
+                        run(cand)
+                    assert np.array_equal(fetch(), want), (cand, rep)
+        finally:
+            lib.rn_ctx_set_conv_tile(ctx.handle, 0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_wide_kernel_random_shapes_against_the_4_wave_kernel(seed):
+    """Random geometry (image size, stride, padding, channel counts that leave ragged M and N
+    tiles, 1x1 and 3x3, with and without residual): every wide tile == 4-wave tile, bit for bit."""
+    from resnet_c_amd import _lib as L
+    g = np.random.default_rng(4000 + seed)
+    k = int(g.choice([1, 3]))
+    s = int(g.choice([1, 2]))
+    p = int(g.choice([0, 1])) if k == 3 else 0
+    B, H, W = int(g.integers(1, 9)), int(g.integers(7, 30)), int(g.integers(7, 30))
+    Cin, Cout = 64 * int(g.integers(1, 5)), 8 * int(g.integers(1, 50))
+    x, w = rnd((B, Cin, H, W), seed), rnd((Cout, Cin, k, k), seed + 1) / np.sqrt(Cin * k * k)
+    ho, wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = rnd((B, Cout, ho, wo), seed + 2) if seed % 2 else None
+    sc, sh = g.random(Cout, dtype=np.float32) + 0.5, g.standard_normal(Cout, dtype=np.float32)
+    ctx, lib = R.get_ctx(), L.lib()
+    try:
+        lib.rn_ctx_set_conv_tile(ctx.handle, 4)
+        want = ops.conv2d_nhwc_bf16(x, w, s, p, sc, sh, res, True)
+        for cand in (9, 10, 11, 12):
+            lib.rn_ctx_set_conv_tile(ctx.handle, cand)
+            assert np.array_equal(ops.conv2d_nhwc_bf16(x, w, s, p, sc, sh, res, True), want), (cand, B, H, W, Cin, Cout, k, s, p)
     finally:
         lib.rn_ctx_set_conv_tile(ctx.handle, 0)
 
