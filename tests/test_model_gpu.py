@@ -349,6 +349,41 @@ def test_fused_stem_pool_changes_launches_not_results(state50, finch, golden_dir
         m.close()
 
 
+def test_two_stream_forward_under_capture_pipeline_and_shards(state50, finch):
+    """bf16 models run a batch of >= 128 images as two halves on two streams (fork / join events).
+    The same forward captured as a hipGraph (a cross-stream capture), fed through the host
+    pipeline, and run by the sharded driver must give the eager forward's bits."""
+    m = R.NativeModel("resnet50", state=state50, dtype="bf16")
+    try:
+        assert m.streams() == 2
+        B = 128
+        x = R.weights.generate_input(B, seed=97)
+        x[100] = finch[0]
+        want = m.forward(x, fused=True)
+        m.set_streams(1)
+        assert np.array_equal(m.forward(x, fused=True), want)
+        m.set_streams(2)
+        xd = R.FloatTensor.from_numpy(x, R.Device.GPU)
+        out = R.FloatTensor((B, 1000), R.Device.GPU)
+        g = R.Graph(m, xd.data(), B, out.data(), fused=True)
+        R._lib.check(R._lib.lib().rn_memset(m.ctx.handle, out.data(), 0, B * 4000), "memset", m.ctx.handle)
+        g.launch(); g.launch(); m.ctx.sync()
+        assert np.array_equal(out.numpy(), want)
+        g.close()
+        pipe = R.Pipeline(m, B, fused=True)
+        got = list(pipe.run([x, x[::-1].copy()]))
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want[::-1])
+        pipe.close()
+    finally:
+        m.close()
+    sh = R.ShardedModel([0, 0], "resnet50", state=state50, dtype="bf16")
+    try:
+        logits, top1 = sh.forward(x[:10], fused=True)
+        assert np.array_equal(logits, want[:10]) and np.array_equal(top1, want[:10].argmax(1).astype(np.uint64))
+    finally:
+        sh.close()
+
+
 def test_sharded_model_equals_whole_batch(state50, model50, finch):
     """rn_shard_*: one host thread + context + model per listed device, contiguous batch split,
     logits concatenated on the host (main.cu:228-254 over several devices).  A
