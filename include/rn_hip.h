@@ -324,8 +324,16 @@ RN_API int rn_stem_pool_pack_weight_dt(rn_ctx *ctx, int dtype, const float *weig
 RN_API int rn_stem_pool_forward_dt(rn_ctx *ctx, int dtype, const void *inp_padded, void *out,
                                    const void *packed_weight, const float *scale, const float *shift,
                                    int relu, uint64_t B, uint64_t Hp, uint64_t Wp);
+/* The same launch reading the reference's fp32 NCHW image [B,in_channels,H,W] directly: the zero
+ * border, the channel interleave and the conversion to `dtype` happen while the input patch is
+ * assembled in LDS, so no layout kernel and no padded copy of the image are needed.  W % 4 == 0. */
+RN_API int rn_stem_pool_nchw_forward_dt(rn_ctx *ctx, int dtype, const float *inp_nchw, void *out,
+                                        const void *packed_weight, const float *scale,
+                                        const float *shift, int relu, uint64_t B,
+                                        uint64_t in_channels, uint64_t H, uint64_t W);
 /* Fused mode: use it for conv1 + bn1 + relu + maxpool (default on; fp32 needs the exact-K stem
- * image, rn_model_set_stem_exact).  Invalidates the tuned tiles. */
+ * image, rn_model_set_stem_exact).  on == 2: through rn_stem_pool_nchw_forward_dt, the input
+ * layout launch disappears as well.  Invalidates the tuned tiles. */
 RN_API int rn_model_set_stem_pool_fusion(rn_model *m, int on);
 
 /* ---- fused pair: out = epilogue(conv(inp, W1) + conv1x1(inp2, W2)) ------------------

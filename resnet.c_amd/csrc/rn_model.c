@@ -539,7 +539,7 @@ int rn_model_get_streams(const rn_model *m) { return m ? m->streams : 0; }
 int rn_model_set_stem_pool_fusion(rn_model *m, int on)
 {
     if (!m) return RN_ERR_INVALID;
-    m->stem_pool = on ? 1 : 0;
+    m->stem_pool = on < 0 ? 0 : on > 2 ? 2 : on; /* 2: fetch the patches from the NCHW input */
     m->tuned_B = 0;
     return RN_OK;
 }
@@ -758,18 +758,24 @@ static int op_add(rn_model *m, const char *layer, float *y, const float *shortcu
 /* conv1 + bn1 + ReLU + max-pool (main.cu:179-192) as one launch: x4 (physically padded image)
  * -> p0 (pooled, where the separate max-pool writes too).  Algorithmic work: the stem's FLOPs
  * (no halo), the image read once, the pooled tensor written once. */
-static int op_stem_pool(rn_model *m, const rn_conv *stem, uint64_t B, uint64_t Hp, uint64_t Wp,
-                        uint64_t ho, uint64_t wo)
+static int op_stem_pool(rn_model *m, const rn_conv *stem, const float *input_nchw, uint64_t B,
+                        uint64_t Hp, uint64_t Wp, uint64_t ho, uint64_t wo)
 {
     const double es = (double)elem_size(m);
     const uint64_t ph = rn_conv_output_size(ho, 3, 2, 1), pw = rn_conv_output_size(wo, 3, 2, 1);
     const double cs = m->dtype == RN_DTYPE_BF16 ? 4.0 : 3.0;
     TRY(prof_begin(m, "conv2d+epilogue+maxpool", "conv1+maxpool",
                    2.0 * (double)(B * ho * wo) * (double)stem->cout * (double)(stem->cin * stem->k * stem->k),
-                   es * ((double)(B * Hp * Wp) * cs + (double)(stem->cout * stem->cin * stem->k * stem->k) +
-                         (double)(B * ph * pw * stem->cout))));
-    TRY(rn_stem_pool_forward_dt(m->run, m->dtype, m->v.x4, m->v.p0, m->stem_pool_packed, stem->scale,
-                                stem->shift, 1, B, Hp, Wp));
+                   (input_nchw ? 4.0 * (double)(B * (Hp - 6) * (Wp - 6) * stem->cin)
+                               : es * (double)(B * Hp * Wp) * cs) +
+                       es * ((double)(stem->cout * stem->cin * stem->k * stem->k) +
+                             (double)(B * ph * pw * stem->cout))));
+    if (input_nchw) /* stem_pool == 2: the patch fetch reads the caller's NCHW fp32 image itself */
+        TRY(rn_stem_pool_nchw_forward_dt(m->run, m->dtype, input_nchw, m->v.p0, m->stem_pool_packed,
+                                         stem->scale, stem->shift, 1, B, stem->cin, Hp - 6, Wp - 6));
+    else
+        TRY(rn_stem_pool_forward_dt(m->run, m->dtype, m->v.x4, m->v.p0, m->stem_pool_packed, stem->scale,
+                                    stem->shift, 1, B, Hp, Wp));
     return prof_end(m);
 }
 
@@ -874,14 +880,17 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
         if (bf16) {
             /* bf16 stem: [B,230,230,4] image with its own 3-pixel zero border, padding 0 */
             const uint64_t border = stem->pad;
-            STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0,
-                            (double)B * (4.0 * 3 * 224 * 224 + es * 230 * 230 * 4)));
-            STEP(rn_nchw_to_nhwc_pad_dt(m->run, m->dtype, input_nchw, m->v.x4, B, 3, H, W, 4, border));
-            STEP(prof_end(m));
+            const int from_nchw = m->stem_pool == 2;
+            if (!from_nchw) {
+                STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0,
+                                (double)B * (4.0 * 3 * 224 * 224 + es * 230 * 230 * 4)));
+                STEP(rn_nchw_to_nhwc_pad_dt(m->run, m->dtype, input_nchw, m->v.x4, B, 3, H, W, 4, border));
+                STEP(prof_end(m));
+            }
             ho = rn_conv_output_size(H + 2 * border, stem->k, stem->stride, 0);
             wo = rn_conv_output_size(W + 2 * border, stem->k, stem->stride, 0);
             if (m->stem_pool) {
-                STEP(op_stem_pool(m, stem, B, H + 2 * border, W + 2 * border, ho, wo));
+                STEP(op_stem_pool(m, stem, from_nchw ? input_nchw : NULL, B, H + 2 * border, W + 2 * border, ho, wo));
                 fused_pool = 1;
             } else {
                 rn_epilogue ep;
@@ -893,7 +902,10 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
             const uint64_t border = m->stem_exact ? stem->pad : 0;
             const uint64_t sh = H + 2 * border, sw = W + 2 * border;
             const int64_t form = m->stem_exact ? RN_PAD_EXACT : -1;
-            if (m->stem_exact) {
+            const int from_nchw = mode == RN_FWD_FUSED && m->stem_pool == 2 && m->stem_exact;
+            if (from_nchw) {
+                /* no layout launch */
+            } else if (m->stem_exact) {
                 STEP(prof_begin(m, "nchw_to_nhwc3", "input", 0.0,
                                 4.0 * (double)B * (3.0 * 224 * 224 + 3.0 * 230 * 230)));
                 STEP(rn_nchw_to_nhwc_pad_dt(m->run, RN_DTYPE_F32, input_nchw, m->v.x4, B, 3, H, W, 3,
@@ -902,11 +914,11 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
                 STEP(prof_begin(m, "nchw_to_nhwc4", "input", 0.0, 4.0 * (double)(B * 224 * 224 * 7)));
                 STEP(rn_nchw_to_nhwc_pad(m->run, input_nchw, m->v.x4, B, 3, H, W, 4));
             }
-            STEP(prof_end(m));
+            if (!from_nchw) STEP(prof_end(m));
             ho = rn_conv_output_size(H, stem->k, stem->stride, stem->pad);
             wo = rn_conv_output_size(W, stem->k, stem->stride, stem->pad);
             if (mode == RN_FWD_FUSED && m->stem_pool && m->stem_exact) {
-                STEP(op_stem_pool(m, stem, B, sh, sw, ho, wo));
+                STEP(op_stem_pool(m, stem, from_nchw ? input_nchw : NULL, B, sh, sw, ho, wo));
                 fused_pool = 1;
             } else if (mode == RN_FWD_FUSED) {
                 rn_epilogue ep;

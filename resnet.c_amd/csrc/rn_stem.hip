@@ -54,6 +54,7 @@ struct StemParams {
     const float *shift;
     void *out;           // [B][PH][PW][64]
     int B, Hp, Wp, Ho, Wo, PH, PW;
+    int Cin;             // NCHW input only: channels of the image (1..3)
     int relu;
     unsigned items;      // B * ceil(PH / 2)
     int pairs;           // ceil(PH / 2)
@@ -76,7 +77,11 @@ struct Cfg<bf16_t> {
     static constexpr int STEPS_ROW = 2;
 };
 
-template <typename T>
+// NCHW_IN: p.in is the reference's fp32 NCHW image [B][Cin][H][W] itself (H = Hp - 6, W = Wp - 6):
+// the patch is assembled in LDS from its channel rows -- zero border, channel interleave and the
+// conversion to T included -- and the separate layout kernel and its padded copy of the image
+// disappear.
+template <typename T, bool NCHW_IN>
 __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
 {
     using C = Cfg<T>;
@@ -114,6 +119,11 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
     const float sh = p.shift ? p.shift[n] : 0.f;
 
     for (int i = t; i < 2 * pooled_n; i += 512) pooled0[i] = 0.f;
+    if constexpr (NCHW_IN) {  // the patches' border pixels and pad channel are zero and stay zero
+        for (int i = t * 16; i < 2 * patch_bytes; i += 512 * 16)
+            *reinterpret_cast<i32x4 *>(lds + i) = i32x4{0, 0, 0, 0};
+        __syncthreads();
+    }
 
     // The input patch of an item: rows [row0, row0 + 15) of the padded image clipped to the image --
     // one contiguous block of memory -- fetched as 16-byte pieces from the 16-byte boundary below
@@ -121,7 +131,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
     // starts 16 or 24 bytes into the array).  All pieces of a thread are independent loads, issued for
     // item i+1 before the contraction of item i and written to LDS after it: the fetch hides
     // behind the matrix work instead of standing in front of it.
-    constexpr int kPieces = 6;  // 512 threads x 16 B x 6 = 48 KB >= 15 rows of 266 fp32 pixels
+    // 512 threads x 16 B x 6 = 48 KB >= 15 rows of 266 fp32 pixels; NCHW: 6 x 8 waves >= 45 channel rows
+    constexpr int kPieces = 6;
     i32x4 stage[kPieces];
     auto patch_src = [&](unsigned item, const char *&src, int &dst_off, int &nbytes, int &base) {
         const int b = (int)(item / (unsigned)p.pairs), pj = (int)(item % (unsigned)p.pairs);
@@ -136,26 +147,67 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
         dst_off = base + (lo - row0) * rowb - mis;
         nbytes = (hi - lo) * rowb + mis;
     };
+    // NCHW_IN: a wave fetches one channel row of the patch per piece -- lane q its pixels 4q..4q+3
+    // (one 16-byte load; lanes past W/4 idle) -- piece k of wave w the row-channel rc = w + 8k =
+    // (patch row r) * Cin + c, i.e. channel c of image row row0 + r - 3.  Stored as four elements
+    // of T at pixel stride; rows outside the image are stored as zeros (the buffer held another
+    // item's rows).
+    const int W4 = (p.Wp - 6) >> 2;
+    auto unit_of = [&](int k, int &r, int &c, int &q) -> bool {
+        const int rc = (t >> 6) + 8 * k;
+        q = t & 63;
+        r = p.Cin == 3 ? (rc * 43) >> 7 : p.Cin == 2 ? rc >> 1 : rc;  // rc / Cin for rc < 48
+        c = rc - r * p.Cin;
+        return r < kPatchRows && q < W4;
+    };
     auto patch_fetch = [&](unsigned item) {
-        const char *src;
-        int dst_off, nbytes, base;
-        patch_src(item, src, dst_off, nbytes, base);
+        if constexpr (NCHW_IN) {
+            const int b = (int)(item / (unsigned)p.pairs), pj = (int)(item % (unsigned)p.pairs);
+            const int row0 = 2 * (4 * pj - 1), H = p.Hp - 6, W = p.Wp - 6;
 #pragma unroll
-        for (int k = 0; k < kPieces; ++k) {
-            const int o = (k * 512 + t) * 16;
-            stage[k] = *reinterpret_cast<const i32x4 *>(src + (o < nbytes ? o : 0));
+            for (int k = 0; k < kPieces; ++k) {
+                int r, c, q;
+                const bool ok = unit_of(k, r, c, q);
+                const int ih = row0 + r - 3;
+                const bool real = ok && ih >= 0 && ih < H;
+                const float *src = static_cast<const float *>(p.in) +
+                                   (((size_t)b * p.Cin + (real ? c : 0)) * H + (real ? ih : 0)) * W + (real ? 4 * q : 0);
+                const i32x4 v = *reinterpret_cast<const i32x4 *>(src);
+                stage[k] = real ? v : i32x4{0, 0, 0, 0};
+            }
+        } else {
+            const char *src;
+            int dst_off, nbytes, base;
+            patch_src(item, src, dst_off, nbytes, base);
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) {
+                const int o = (k * 512 + t) * 16;
+                stage[k] = *reinterpret_cast<const i32x4 *>(src + (o < nbytes ? o : 0));
+            }
         }
     };
     auto patch_store = [&](unsigned item, int buf) -> int {
-        const char *src;
-        int dst_off, nbytes, base;
-        patch_src(item, src, dst_off, nbytes, base);
+        if constexpr (NCHW_IN) {
 #pragma unroll
-        for (int k = 0; k < kPieces; ++k) {
-            const int o = (k * 512 + t) * 16;
-            if (o < nbytes) *reinterpret_cast<i32x4 *>(lds + buf * patch_bytes + dst_off + o) = stage[k];
+            for (int k = 0; k < kPieces; ++k) {
+                int r, c, q;
+                if (!unit_of(k, r, c, q)) continue;
+                T *dst = reinterpret_cast<T *>(lds + buf * patch_bytes + 16 + r * rowb) + (3 + 4 * q) * C::CS + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dst[i * C::CS] = (T)__int_as_float(stage[k][i]);
+            }
+            return buf * patch_bytes + 16;
+        } else {
+            const char *src;
+            int dst_off, nbytes, base;
+            patch_src(item, src, dst_off, nbytes, base);
+#pragma unroll
+            for (int k = 0; k < kPieces; ++k) {
+                const int o = (k * 512 + t) * 16;
+                if (o < nbytes) *reinterpret_cast<i32x4 *>(lds + buf * patch_bytes + dst_off + o) = stage[k];
+            }
+            return buf * patch_bytes + base;
         }
-        return buf * patch_bytes + base;
     };
     // pooled rows of a finished item -> global, then cleared for the item after next
     auto pooled_out = [&](unsigned item, float *pooled) {
@@ -372,29 +424,35 @@ int rn_stem_pool_pack_weight_dt(rn_ctx *ctx, int dtype, const float *weight_oihw
     return rn_after_launch(ctx, "rn_stem_pool_pack_weight_dt");
 }
 
-int rn_stem_pool_forward_dt(rn_ctx *ctx, int dtype, const void *inp_padded, void *out,
-                            const void *packed_weight, const float *scale, const float *shift,
-                            int relu, uint64_t B, uint64_t Hp, uint64_t Wp)
+// shared by the two entry points: nchw = the image is the reference's fp32 NCHW tensor, Cin channels
+static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, const void *packed_weight,
+                            const float *scale, const float *shift, int relu, uint64_t B, uint64_t Hp,
+                            uint64_t Wp, bool nchw, uint64_t Cin, const char *what)
 {
-    RN_ENTER(ctx);
     if (B == 0) return RN_OK;
     RN_REQUIRE(ctx, dtype == RN_DTYPE_F32 || dtype == RN_DTYPE_BF16, "unknown dtype");
-    RN_REQUIRE(ctx, inp_padded && out && packed_weight && inp_padded != out, "null or aliased tensor");
+    RN_REQUIRE(ctx, inp && out && packed_weight && inp != out, "null or aliased tensor");
     RN_REQUIRE(ctx, Hp >= 7 && Wp >= 7 && Hp < (1u << 14) && Wp < (1u << 14), "image size out of range");
     const uint64_t Ho = rn_conv_output_size(Hp, 7, 2, 0), Wo = rn_conv_output_size(Wp, 7, 2, 0);
     const uint64_t PH = rn_conv_output_size(Ho, 3, 2, 1), PW = rn_conv_output_size(Wo, 3, 2, 1);
     RN_REQUIRE(ctx, Wo / 8 + (Wo + 31) / 32 <= 4 * kMaxTiles, "image too wide for the fused stem (conv output width <= 128)");
     RN_REQUIRE(ctx, Wo % 8 == 0, "the fused stem needs a conv output width that is a multiple of 8");
     const int es = dtype == RN_DTYPE_BF16 ? 2 : 4, cs = dtype == RN_DTYPE_BF16 ? 4 : 3;
-    RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(inp_padded) | reinterpret_cast<uintptr_t>(out) |
+    RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out) |
                       reinterpret_cast<uintptr_t>(packed_weight)) & 15) == 0,
                "tensors must be 16-byte aligned");
-    // the patch copy moves 16-byte (bf16) / 8-byte (fp32) granules of whole image rows
-    RN_REQUIRE(ctx, (Wp * cs * es) % (dtype == RN_DTYPE_BF16 ? 16 : 8) == 0,
-               "padded image width must make rows a multiple of 16 bytes (bf16) / 8 bytes (fp32)");
+    if (nchw) {
+        RN_REQUIRE(ctx, Cin >= 1 && Cin <= 3, "the fused stem takes 1..3 input channels");
+        RN_REQUIRE(ctx, (Wp - 6) % 4 == 0, "NCHW input: the image width must be a multiple of 4");
+        RN_REQUIRE(ctx, (Wp - 6) / 4 <= 64, "image too wide for the fused stem (NCHW fetch: W <= 256)");
+    } else {
+        // the patch copy moves 16-byte pieces from the 16-byte boundary below a row start
+        RN_REQUIRE(ctx, (Wp * cs * es) % (dtype == RN_DTYPE_BF16 ? 16 : 8) == 0,
+                   "padded image width must make rows a multiple of 16 bytes (bf16) / 8 bytes (fp32)");
+    }
     RN_REQUIRE(ctx, B * Hp * Wp * cs < (1ull << 40) && B * PH * PW < (1ull << 31), "tensor too large");
     StemParams p;
-    p.in = inp_padded;
+    p.in = inp;
     p.w = packed_weight;
     p.scale = scale;
     p.shift = shift;
@@ -406,6 +464,7 @@ int rn_stem_pool_forward_dt(rn_ctx *ctx, int dtype, const void *inp_padded, void
     p.Wo = (int)Wo;
     p.PH = (int)PH;
     p.PW = (int)PW;
+    p.Cin = (int)Cin;
     p.relu = relu;
     p.pairs = (int)rn_ceil_div(PH, 2);
     p.items = (unsigned)(B * (uint64_t)p.pairs);
@@ -415,20 +474,43 @@ int rn_stem_pool_forward_dt(rn_ctx *ctx, int dtype, const void *inp_padded, void
     RN_REQUIRE(ctx, lds_bytes <= 160 * 1024, "image too wide for the fused stem (LDS)");
     unsigned grid = 256u;  // one block per CU (registers): persistent, items grid-stride
     if (grid > p.items) grid = p.items;
+    const bool bf = dtype == RN_DTYPE_BF16;
+    const void *fn = bf ? (nchw ? (const void *)stem_pool_kernel<bf16_t, true> : (const void *)stem_pool_kernel<bf16_t, false>)
+                        : (nchw ? (const void *)stem_pool_kernel<float, true> : (const void *)stem_pool_kernel<float, false>);
     // more than 64 KB of dynamic LDS has to be allowed once per kernel and device (not a stream
     // operation: done on the first call, which a capturing caller makes eagerly anyway)
-    int *allowed = &ctx->occupancy[250 + (dtype == RN_DTYPE_BF16 ? 1 : 0)];
-    if (lds_bytes > 64 * 1024 && *allowed < (int)lds_bytes) {
-        RN_HIP_TRY(ctx, hipFuncSetAttribute(dtype == RN_DTYPE_BF16 ? (const void *)stem_pool_kernel<bf16_t>
-                                                                   : (const void *)stem_pool_kernel<float>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        *allowed = 160 * 1024;
+    int *allowed = &ctx->occupancy[248 + (bf ? 1 : 0) + (nchw ? 2 : 0)];
+    if (lds_bytes > 64 * 1024 && *allowed == 0) {
+        RN_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        *allowed = 1;
     }
-    if (dtype == RN_DTYPE_BF16)
-        stem_pool_kernel<bf16_t><<<grid, 512, lds_bytes, ctx->stream>>>(p);
+    if (bf && nchw)
+        stem_pool_kernel<bf16_t, true><<<grid, 512, lds_bytes, ctx->stream>>>(p);
+    else if (bf)
+        stem_pool_kernel<bf16_t, false><<<grid, 512, lds_bytes, ctx->stream>>>(p);
+    else if (nchw)
+        stem_pool_kernel<float, true><<<grid, 512, lds_bytes, ctx->stream>>>(p);
     else
-        stem_pool_kernel<float><<<grid, 512, lds_bytes, ctx->stream>>>(p);
-    return rn_after_launch(ctx, "rn_stem_pool_forward_dt");
+        stem_pool_kernel<float, false><<<grid, 512, lds_bytes, ctx->stream>>>(p);
+    return rn_after_launch(ctx, what);
+}
+
+int rn_stem_pool_forward_dt(rn_ctx *ctx, int dtype, const void *inp_padded, void *out,
+                            const void *packed_weight, const float *scale, const float *shift,
+                            int relu, uint64_t B, uint64_t Hp, uint64_t Wp)
+{
+    RN_ENTER(ctx);
+    return stem_pool_launch(ctx, dtype, inp_padded, out, packed_weight, scale, shift, relu, B, Hp, Wp, false, 3,
+                            "rn_stem_pool_forward_dt");
+}
+
+int rn_stem_pool_nchw_forward_dt(rn_ctx *ctx, int dtype, const float *inp_nchw, void *out,
+                                 const void *packed_weight, const float *scale, const float *shift,
+                                 int relu, uint64_t B, uint64_t in_channels, uint64_t H, uint64_t W)
+{
+    RN_ENTER(ctx);
+    return stem_pool_launch(ctx, dtype, inp_nchw, out, packed_weight, scale, shift, relu, B, H + 6, W + 6, true,
+                            in_channels, "rn_stem_pool_nchw_forward_dt");
 }
 
 }  // extern "C"

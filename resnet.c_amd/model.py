@@ -273,8 +273,9 @@ class NativeModel:
     def streams(self) -> int:
         return int(L.lib().rn_model_get_streams(self.handle))
 
-    def set_stem_pool_fusion(self, on: bool) -> None:
-        """Fused mode: conv1 + bn1 + relu + maxpool as one launch (default on)."""
+    def set_stem_pool_fusion(self, on) -> None:
+        """Fused mode: conv1 + bn1 + relu + maxpool as one launch (default on); 2 = that launch
+        reads the NCHW input itself, no layout launch in front of it."""
         L.check(L.lib().rn_model_set_stem_pool_fusion(self.handle, int(on)), "rn_model_set_stem_pool_fusion")
 
     def set_front_parts(self, parts: int) -> None:

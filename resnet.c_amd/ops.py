@@ -315,10 +315,12 @@ def pool_nhwc_bf16(x, k, stride=1, pad=0, is_max=True) -> np.ndarray:
     return y.reshape(B, ho, wo, C).transpose(0, 3, 1, 2).copy()
 
 
-def stem_pool(x, w, scale=None, shift=None, relu_: bool = True, bf16: bool = False) -> np.ndarray:
+def stem_pool(x, w, scale=None, shift=None, relu_: bool = True, bf16: bool = False,
+              from_nchw: bool = False) -> np.ndarray:
     """conv 7x7/2 pad 3 + per-channel affine + ReLU + max-pool 3x3/2/1 through the fused launch
-    (rn_stem_pool_pack_weight_dt + rn_nchw_to_nhwc_pad_dt + rn_stem_pool_forward_dt).  NCHW fp32
-    host arrays in, NCHW fp32 host array [B,64,PH,PW] out."""
+    (rn_stem_pool_pack_weight_dt + rn_nchw_to_nhwc_pad_dt + rn_stem_pool_forward_dt, or with
+    ``from_nchw`` rn_stem_pool_nchw_forward_dt on the NCHW image itself).  NCHW fp32 host arrays
+    in, NCHW fp32 host array [B,64,PH,PW] out."""
     from .tensor import _DeviceBuffer
     ctx, lib = get_ctx(), L.lib()
     B, Cin, H, W = x.shape
@@ -328,16 +330,22 @@ def stem_pool(x, w, scale=None, shift=None, relu_: bool = True, bf16: bool = Fal
     ho, wo = conv_output_size(Hp, 7, 2, 0), conv_output_size(Wp, 7, 2, 0)
     ph, pw = conv_output_size(ho, 3, 2, 1), conv_output_size(wo, 3, 2, 1)
     xin = FloatTensor.from_numpy(np.ascontiguousarray(x, dtype=np.float32), Device.GPU)
-    xp = _DeviceBuffer(ctx, B * Hp * Wp * cpad * es)
-    L.check(lib.rn_nchw_to_nhwc_pad_dt(ctx.handle, dt, xin.data(), xp.ptr, B, Cin, H, W, cpad, 3), "pad", ctx.handle)
+    if not from_nchw:
+        xp = _DeviceBuffer(ctx, B * Hp * Wp * cpad * es)
+        L.check(lib.rn_nchw_to_nhwc_pad_dt(ctx.handle, dt, xin.data(), xp.ptr, B, Cin, H, W, cpad, 3), "pad", ctx.handle)
     wd = FloatTensor.from_numpy(np.ascontiguousarray(w, dtype=np.float32), Device.GPU)
     wp = _DeviceBuffer(ctx, int(lib.rn_stem_pool_packed_weight_numel(dt)) * es)
     L.check(lib.rn_stem_pool_pack_weight_dt(ctx.handle, dt, wd.data(), wp.ptr, Cin), "pack", ctx.handle)
     sc = FloatTensor.from_numpy(np.asarray(scale, dtype=np.float32), Device.GPU) if scale is not None else None
     sh = FloatTensor.from_numpy(np.asarray(shift, dtype=np.float32), Device.GPU) if shift is not None else None
     out = _DeviceBuffer(ctx, B * ph * pw * 64 * es)
-    L.check(lib.rn_stem_pool_forward_dt(ctx.handle, dt, xp.ptr, out.ptr, wp.ptr, sc.data() if sc else None,
-                                        sh.data() if sh else None, int(relu_), B, Hp, Wp), "stem_pool", ctx.handle)
+    if from_nchw:
+        L.check(lib.rn_stem_pool_nchw_forward_dt(ctx.handle, dt, xin.data(), out.ptr, wp.ptr,
+                                                 sc.data() if sc else None, sh.data() if sh else None,
+                                                 int(relu_), B, Cin, H, W), "stem_pool_nchw", ctx.handle)
+    else:
+        L.check(lib.rn_stem_pool_forward_dt(ctx.handle, dt, xp.ptr, out.ptr, wp.ptr, sc.data() if sc else None,
+                                            sh.data() if sh else None, int(relu_), B, Hp, Wp), "stem_pool", ctx.handle)
     host = np.empty(B * ph * pw * 64, dtype=np.uint16 if bf16 else np.float32)
     L.check(lib.rn_memcpy_d2h(ctx.handle, host.ctypes.data, out.ptr, host.nbytes), "d2h", ctx.handle)
     if bf16:

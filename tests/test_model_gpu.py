@@ -345,6 +345,14 @@ def test_fused_stem_pool_changes_launches_not_results(state50, finch, golden_dir
         # batch invariance holds for the fused launch too
         m.set_stem_pool_fusion(True)
         assert np.array_equal(m.forward(x[2:3], fused=True), fused[2:3])
+        # 2: the launch reads the NCHW input itself -- the layout launch goes, the bits stay
+        m.set_stem_pool_fusion(2)
+        m.set_profiling(True)
+        direct = m.forward(x, fused=True)
+        n_direct = [r["op"] for r in m.profile()]
+        m.set_profiling(False)
+        assert np.array_equal(direct, fused)
+        assert len(n_direct) == len(n_fused) - 1 and not any(o.startswith("nchw_to_nhwc") for o in n_direct)
     finally:
         m.close()
 

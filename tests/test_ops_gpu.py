@@ -590,6 +590,8 @@ def test_fused_stem_and_maxpool_match_the_four_reference_ops(shape, bf16):
     tol = (2 ** -7 if bf16 else 2e-6 * np.sqrt(Cin * 49)) * float(np.abs(want).max()) + 1e-6
     assert np.abs(got - want).max() <= tol
     assert (got >= 0).all() and np.array_equal(got, ops.stem_pool(x, w, sc, sh, True, bf16=bf16))
+    # rn_stem_pool_nchw_forward_dt assembles the same patch from the NCHW image: the same bits
+    assert np.array_equal(got, ops.stem_pool(x, w, sc, sh, True, bf16=bf16, from_nchw=True))
     # against the engine's own unfused kernels: same products, another summation order
     if not bf16 and Cin == 3:
         conv = ops.conv2d_nhwc_fused(x, w, 2, 3, sc, sh, None, True)
@@ -601,3 +603,5 @@ def test_fused_stem_refuses_what_it_cannot_do():
     x, w = rnd((1, 3, 30, 30), 5), rnd((64, 3, 7, 7), 6)
     with pytest.raises(L.RnError):      # conv output width 15: not a multiple of 8
         ops.stem_pool(x, w)
+    with pytest.raises(L.RnError):
+        ops.stem_pool(x, w, from_nchw=True)
