@@ -117,17 +117,21 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
     static_assert(WM * WN == 8, "eight waves");
     constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
     constexpr int MI = TM / 32, NI = TN / 32;
-    constexpr int PA = BM / 64, PB = BN / 64;  // 1-KiB DMA pieces per wave and K tile
+    // BM need not be a multiple of 64 (224 = 7 fragments: 50,176 rows are 224 tiles, one round of
+    // 256 CUs at 7/8 of the 256-row tile's time); the A slot is, its last rows are never fetched
+    constexpr int AM = (BM + 63) / 64 * 64;
+    constexpr int PA = AM / 64, PB = BN / 64;  // 1-KiB DMA pieces per wave and K tile
     static_assert(PA >= 1 && PB >= 1 && MI >= 1 && NI >= 1, "tile too small for eight waves");
-    constexpr int A_SLOT = BM * 128, B_SLOT = BN * 128;  // bytes of one K tile of A / of B
+    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile in whole fragments");
+    constexpr int A_SLOT = AM * 128, B_SLOT = BN * 128;  // bytes of one K tile of A / of B
     constexpr int SA = 3;
     constexpr int SB = 3 * (A_SLOT + B_SLOT) <= 160 * 1024 ? 3 : 2;
     constexpr int LDS_BYTES = SA * A_SLOT + SB * B_SLOT;
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     // epilogue staging: the fp32 tile in one pass, or its two halves of BM/2 rows
-    constexpr int CPASS = BM * BN * 4 <= LDS_BYTES ? 1 : 2;
-    constexpr int EROWS = BM / CPASS;
-    static_assert(EROWS * BN * 4 <= LDS_BYTES && EROWS % TM == 0, "epilogue staging");
+    constexpr int CPASS = AM * BN * 4 <= LDS_BYTES ? 1 : 2;
+    constexpr int EROWS = AM / CPASS;
+    static_assert(EROWS * BN * 4 <= LDS_BYTES && EROWS % 32 == 0, "epilogue staging");
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
 
     stamp(p.stamps, 0);
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
         const int r = 8 * (8 * j + wave) + prow;
         const int chunk = (pc ^ ((r >> 1) & 7)) * 16;
         const int m = m0 + r;
-        if (m < p.M) {
+        if (r < BM && m < p.M) {
             const int b = p.HoWo == 1 ? m : (int)(__umulhi((unsigned)m, p.mul_hw) >> p.shr_hw);
             const int rem = m - b * p.HoWo;
             const int oh = p.Wo == 1 ? rem : (int)(__umulhi((unsigned)rem, p.mul_w) >> p.shr_w);
@@ -390,18 +394,19 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int m = m0 + row0 + rr + s * RPP;
-            const int off = (col_ok && m < p.M) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
+            const int off = (col_ok && m < p.M && row0 + rr + s * RPP < BM) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
             resv[s] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, off, 0, 0));
         }
-        if (wm * TM >= row0 && wm * TM < row0 + EROWS) {  // wave-uniform
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi) {
+            const int fr = wm * TM + mi * 32 - row0;  // fragment's first row in this pass: wave-uniform
+            if (fr < 0 || fr >= EROWS) continue;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    float *dst = Cs + (wm * TM - row0 + mi * 32 + 4 * lh) * BN + wn * TN + ni * 32 + li;
+            for (int ni = 0; ni < NI; ++ni) {
+                float *dst = Cs + (fr + 4 * lh) * BN + wn * TN + ni * 32 + li;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[mi][ni][e];
-                }
+                for (int e = 0; e < 16; ++e) dst[((e & 3) + 8 * (e >> 2)) * BN] = acc[mi][ni][e];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
                 y = has_res ? y + res[j] : y;
                 v[j] = p.relu ? fmaxf(y, 0.f) : y;
             }
-            const int off = (col_ok && m < p.M) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
+            const int off = (col_ok && m < p.M && row0 + row < BM) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Out<TO>::pack(v)), rsrc_o, off, 0, 0);
         }
         if (pass + 1 < CPASS) __syncthreads();
@@ -436,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
 struct WideTile {
     int bm, bn;
 };
-constexpr WideTile kTiles[] = {{256, 256}, {256, 128}, {128, 256}, {256, 64}};
+constexpr WideTile kTiles[] = {{256, 256}, {256, 128}, {128, 256}, {256, 64}, {224, 256}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
 template <int BM, int BN, int WM, int WN>
@@ -472,6 +477,7 @@ void rn_conv_wide_launch(rn_ctx *ctx, GemmParams &p, int which, bool dual)
     case 0: launch<256, 256, 2, 4>(ctx, p, dual); break;
     case 1: launch<256, 128, 4, 2>(ctx, p, dual); break;
     case 2: launch<128, 256, 2, 4>(ctx, p, dual); break;
-    default: launch<256, 64, 8, 1>(ctx, p, dual); break;
+    case 3: launch<256, 64, 8, 1>(ctx, p, dual); break;
+    default: launch<224, 256, 1, 8>(ctx, p, dual); break;
     }
 }
