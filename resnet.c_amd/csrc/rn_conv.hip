@@ -751,21 +751,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const FinishParams p
 
 bool fits_i32(uint64_t v) { return v < (1ull << 31); }
 
-// n / d == umulhi(n, mul) >> shr for 0 <= n < 2^31, d >= 1 (round-up magic number)
-void fast_div(unsigned d, unsigned *mul, unsigned *shr)
-{
-    if (d <= 1) {  // the kernel special-cases a divisor of 1 (fc, 1x1 outputs)
-        *mul = 0;
-        *shr = 0;
-        return;
-    }
-    unsigned lg = 0;
-    while ((1u << lg) < d) ++lg;
-    const unsigned p = 31 + lg;
-    const uint64_t m = ((1ull << p) + d - 1) / d;
-    *mul = (unsigned)m;
-    *shr = p - 32;
-}
+void fast_div(unsigned d, unsigned *mul, unsigned *shr) { rn_fast_div(d, mul, shr); }
 
 // Blocks of one instantiation that fit a CU at once (registers and LDS) on the context's device,
 // asked once per context and instantiation: the answer lives in the context, not in the process.
@@ -899,6 +885,13 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     if (dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_BF16 && ctx->split_k <= 1) {
         const int nwide = rn_conv_wide_count();
         int which = -1;
+        // 3x3 / 64 -> 64 channels: the strip kernel (weights in registers, input ring in LDS);
+        // the candidate after the wide tiles, and the untuned choice where it applies
+        if ((ctx->conv_tile == 9 + nwide || (ctx->conv_tile == 0 && p.M >= 256 * 256)) && second == nullptr &&
+            rn_conv_strip_eligible(p)) {
+            rn_conv_strip_launch(ctx, p);
+            return rn_after_launch(ctx, what);
+        }
         if (ctx->conv_tile > 8 && ctx->conv_tile <= 8 + nwide) {
             if (rn_conv_wide_eligible(p, ctx->conv_tile - 9)) which = ctx->conv_tile - 9;
         } else if (ctx->conv_tile == 0 && p.nk >= 8 && Cout >= 128) {

@@ -84,11 +84,31 @@ struct Elem<bf16_t> {
 
 }  // namespace rn_gemm
 
+// n / d == umulhi(n, mul) >> shr for 0 <= n < 2^31, d >= 1 (round-up magic number)
+inline void rn_fast_div(unsigned d, unsigned *mul, unsigned *shr)
+{
+    if (d <= 1) {  // the kernels special-case a divisor of 1 (fc, 1x1 outputs)
+        *mul = 0;
+        *shr = 0;
+        return;
+    }
+    unsigned lg = 0;
+    while ((1u << lg) < d) ++lg;
+    const unsigned p = 31 + lg;
+    const uint64_t m = ((1ull << p) + d - 1) / d;
+    *mul = (unsigned)m;
+    *shr = p - 32;
+}
+
 // bf16 contraction on 256-wide block tiles (rn_conv_wide.hip).  which: 0 = 256x256, 1 = 256x128,
 // 2 = 128x256, 3 = 256x64.  Caller has checked rn_conv_wide_eligible().
 int rn_conv_wide_count(void);
 bool rn_conv_wide_eligible(const rn_gemm::GemmParams &p, int which);
 void rn_conv_wide_tile(int which, int *bm, int *bn);
 void rn_conv_wide_launch(rn_ctx *ctx, rn_gemm::GemmParams &p, int which, bool dual);
+// bf16 3x3 / stride 1 / 64 -> 64 channels with the weights in registers and the input in a rolling
+// LDS ring (rn_conv_wide.hip, conv_strip_kernel): the tuner's candidate after the wide tiles.
+bool rn_conv_strip_eligible(const rn_gemm::GemmParams &p);
+void rn_conv_strip_launch(rn_ctx *ctx, const rn_gemm::GemmParams &p);
 
 #endif

@@ -453,6 +453,246 @@ void launch(rn_ctx *ctx, const GemmParams &p, bool dual)
         conv_wide_kernel<bf16_t, BM, BN, WM, WN, false><<<dim3(p.total_tiles), dim3(512), 0, ctx->stream>>>(p);
 }
 
+
+// ---- 3x3 / stride 1 / pad 1, 64 -> 64 channels (conv2 of the first stage): the strip kernel ----
+//
+// With N = 64 the tile kernels above spend their time on per-K-tile overhead: a 256x64 tile has
+// 8 MFMAs per wave between two barriers, and the nine taps re-stage the same input rows nine
+// times (measured: removing eight of the nine A fetches changes nothing -- the loop, not L2, is
+// the limit).  This kernel has no barrier inside a tile and stages every input row once:
+//
+//  * the 9 x 64 x 64 weights live in REGISTERS: wave (nf, mq) owns output channels
+//    32nf .. 32nf+31 and keeps their 36 k-steps as MFMA operands (144 VGPRs), loaded once;
+//  * a block walks a contiguous range of the flattened, zero-PADDED image (pitch W+2, one zero
+//    row between images: position u = (b(H+1) + oh + 1)(W+2) + ow + 1), 256 positions per step.
+//    In that space tap (kh, kw) is the constant shift (kh-1)(W+2) + (kw-1), and every border
+//    tap reads a zero that is really there -- no masks in the loop; the 5 % of positions that
+//    are padding are multiplied and not stored;
+//  * the input lives in a rolling ring of 640 positions x 128 B in LDS, filled by LDS-DMA
+//    (zeros for padding positions through the descriptor's range check): each step first asks for the
+//    next 256 positions, then multiplies the current ones, every input row enters LDS once
+//    per block.  One barrier per step (= per 72 MFMAs of a wave);
+//  * operands swapped: weights are the MFMA's rows, pixels its columns, so a lane ends up with
+//    16 channels of ONE pixel; v_permlane32_swap pairs the two half-waves' 4-channel groups
+//    into 16-byte runs and the lane stores them itself -- no LDS staging of the output.  The
+//    stores of a step are issued after the next step's barrier, so its s_waitcnt vmcnt(0)
+//    waits on nothing fresh.
+//
+// Same k order per output element as the tile kernels (tap-major, 16 channels per MFMA), same
+// products (a*b commutes), so the bits are the same as every other candidate's.
+struct StripParams {
+    const void *in, *w;
+    void *out;
+    const float *scale, *shift;
+    int relu;
+    int B, H, W;
+    int Wp, Hq;  // W + 2, H + 1
+    unsigned mul_wp, shr_wp, mul_hq, shr_hq;
+    int U;       // padded positions: (B * Hq + 1) * Wp
+    int nsteps;  // ceil(U / 256)
+    int in_bytes, out_bytes;
+    unsigned long long *stamps;  // diagnostic only (tools/conv_stamps.py --raw)
+};
+
+constexpr int kRing = 640;       // positions in the LDS ring (5 x 128: 256-position steps wrap every 5)
+constexpr int kStripMargin = 64;  // ring position of a block's first output position; >= W + 3
+
+__global__ __launch_bounds__(512, 2) void conv_strip_kernel(const StripParams p)
+{
+    // ring | scale[64], shift[64] | the weights as they lie in memory (start-up only)
+    __shared__ __attribute__((aligned(16))) char lds[kRing * 128 + 512 + 64 * 576 * 2];
+    stamp(p.stamps, 0);
+    float *const ssl = reinterpret_cast<float *>(lds + kRing * 128);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int nf = wave >> 2, mq = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+    const int prow = lane >> 3, pc = lane & 7;
+
+    // this block's steps: XCD-aware order (neighbouring ranges, which share their halo rows,
+    // on one XCD's L2), remainder steps to the first blocks
+    int nst, ub;
+    {
+        const unsigned total = gridDim.x, v = blockIdx.x;
+        const unsigned q = total >> 3, r = total & 7, xcd = v & 7;
+        const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        const unsigned base = (unsigned)p.nsteps / total, rem = (unsigned)p.nsteps % total;
+        nst = (int)(base + (logical < rem ? 1u : 0u));
+        ub = (int)(logical * base + min(logical, rem)) * 256;
+    }
+
+    if (t < 64) {
+        ssl[t] = p.scale ? p.scale[t] : 1.f;
+        ssl[64 + t] = p.shift ? p.shift[t] : -0.f;  // -0.0 keeps a -0.0 sum
+    }
+
+    const i32x4 srd_in = make_srd(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const unsigned lds_base = (unsigned)(uintptr_t)((lds_void *)lds);
+
+    // Weights: 72 KB, the same for every block.  Fetched as they lie in memory (72 coalesced
+    // 1-KiB DMA pieces) and picked out of LDS -- a lane's 36 fragments are 16 bytes of 36 places
+    // in one 1,152-byte row, and 32 rows per wave instruction straight from global cost the
+    // start of every block 8 us of address-coalescer time.
+    {
+        const i32x4 srd_w = make_srd(p.w, 64 * 576 * 2);
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            dma16(lane * 16, srd_w, (8 * j + wave) * 1024,
+                  lds_base + (unsigned)(kRing * 128 + 512 + (8 * j + wave) * 1024));
+    }
+
+    // padded position u -> pixel index of the NHWC tensor, or -1 for a padding position
+    auto pixel_of = [&](int u) -> int {
+        if (u < 0 || u >= p.U) return -1;
+        const unsigned R = __umulhi((unsigned)u, p.mul_wp) >> p.shr_wp;
+        const int cc = u - (int)R * p.Wp;
+        const unsigned b = __umulhi(R, p.mul_hq) >> p.shr_hq;
+        const int rr = (int)R - (int)b * p.Hq;
+        if (cc < 1 || cc > p.W || rr < 1) return -1;
+        return ((int)b * p.H + rr - 1) * p.W + cc - 1;
+    };
+    // source offset of this lane's 16 bytes of a DMA piece: ring position `slot` holds padded
+    // position u, physical chunk pc holds logical chunk pc ^ ((slot>>1)&7)
+    auto src_off = [&](int u, int slot) -> int {
+        const int g = pixel_of(u);
+        return g < 0 ? kOob : g * 128 + ((pc ^ ((slot >> 1) & 7)) << 4);
+    };
+
+    // ring positions 0 .. 383 = padded positions ub - 64 .. ub + 319: all of step 0's
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int slot = 8 * (8 * j + wave) + prow;
+        dma16(src_off(ub - kStripMargin + slot, slot), srd_in, 0, lds_base + (unsigned)((8 * j + wave) * 1024));
+    }
+
+    i32x4 wreg[36];
+    {
+        wait_and_barrier<0>();
+        const char *wrow = lds + kRing * 128 + 512 + (32 * nf + li) * (576 * 2) + lh * 16;
+#pragma unroll
+        for (int s = 0; s < 36; ++s) wreg[s] = *reinterpret_cast<const i32x4 *>(wrow + s * 32);
+    }
+
+    i32x4 pend[2][2];
+    int pend_off[2] = {kOob, kOob};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) pend[i][h] = i32x4{0, 0, 0, 0};
+    auto flush = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[i][h]), rsrc_o,
+                                                       pend_off[i] == kOob ? kOob : pend_off[i] + 32 * h, 0, 0);
+    };
+
+    int relbase = 0;  // (256 * s) mod 640
+    for (int s = 0; s < nst; ++s) {
+        // this wave's pieces of step s have landed, its reads of step s-1 are back; then all meet
+        wait_and_barrier<0>();
+        if (s < 3) stamp(p.stamps, 1 + 3 * s);
+        flush();  // step s-1's results (nothing at s == 0)
+
+        // next step's 256 positions: four pieces per wave, issued between the taps below
+        int nxt_off[4];
+        unsigned nxt_dst[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int slot0 = relbase + 384 + 8 * (8 * j + wave);  // scalar; ring position of the piece
+            slot0 = slot0 >= kRing ? slot0 - kRing : slot0;
+            slot0 = slot0 >= kRing ? slot0 - kRing : slot0;
+            const int u = ub - kStripMargin + 256 * s + 384 + 8 * (8 * j + wave) + prow;
+            nxt_off[j] = s + 1 < nst ? src_off(u, slot0 + prow) : kOob;
+            nxt_dst[j] = lds_base + (unsigned)(slot0 * 128);
+        }
+        // issued before the multiplication, not inside it: a piece needs a memory round trip
+        // (1.3 us was spent waiting at the barrier when the last one left at 7/8 of the step)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(nxt_off[j], srd_in, 0, nxt_dst[j]);
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+        // 72 (fragment read, MFMA) pairs in k order: n = (4 tap + ks) * 2 + i.  The reads run kDepth
+        // pairs ahead of their MFMA through a ring of fragment registers -- left to itself hipcc
+        // issues each read one MFMA before its use (the 144 weight registers leave it little
+        // room) and the matrix pipe waits out the LDS latency 72 times a step.
+        constexpr int kDepth = 6;
+        i32x4 px[kDepth];
+        int y[9][2];
+        auto read = [&](int n) -> i32x4 {
+            const int tap = n >> 3, ks = (n >> 1) & 3, i = n & 1;
+            if (ks == 0) {
+                const int shift = (tap / 3 - 1) * p.Wp + (tap % 3 - 1);
+                int sb = relbase + kStripMargin + 64 * mq + 32 * i + shift;  // scalar, >= 0
+                sb = sb >= kRing ? sb - kRing : sb;
+                const unsigned r0 = (unsigned)(sb + li);
+                const unsigned r = min(r0, r0 - (unsigned)kRing);  // wraps at most once
+                y[tap][i] = (int)((r << 7) | (((unsigned)lh ^ ((r >> 1) & 7u)) << 4));
+            }
+            return *reinterpret_cast<const i32x4 *>(lds + (y[tap][i] ^ (ks << 5)));
+        };
+#pragma unroll
+        for (int n = 0; n < kDepth; ++n) px[n] = read(n);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < 72; ++n) {
+            acc[n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[n >> 1]),
+                                                                 __builtin_bit_cast(bf16x8, px[n % kDepth]),
+                                                                 acc[n & 1], 0, 0, 0);
+            if (n + kDepth < 72) px[n % kDepth] = read(n + kDepth);
+            __builtin_amdgcn_sched_barrier(0);  // keep the read where it is written, kDepth pairs ahead
+        }
+        if (s < 2) stamp(p.stamps, 2 + 3 * s);
+
+        // results: lane (li, lh) holds channels 32nf + 8j + 4lh + {0..3}, j = 0..3, of pixel li of
+        // each fragment.  Affine + ReLU, bf16, then the half-waves trade 4-channel groups so that
+        // each lane owns channels 32nf + 16h + 8lh + {0..7}: two 16-byte stores per fragment.
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned d[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 sc = *reinterpret_cast<const float4 *>(ssl + 32 * nf + 8 * j + 4 * lh);
+                const float4 sh = *reinterpret_cast<const float4 *>(ssl + 64 + 32 * nf + 8 * j + 4 * lh);
+                float v[4] = {fmaf(acc[i][4 * j], sc.x, sh.x), fmaf(acc[i][4 * j + 1], sc.y, sh.y),
+                              fmaf(acc[i][4 * j + 2], sc.z, sh.z), fmaf(acc[i][4 * j + 3], sc.w, sh.w)};
+                typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    bf16x2 o;
+                    o[0] = (bf16_t)(p.relu ? fmaxf(v[2 * c], 0.f) : v[2 * c]);
+                    o[1] = (bf16_t)(p.relu ? fmaxf(v[2 * c + 1], 0.f) : v[2 * c + 1]);
+                    d[j][c] = __builtin_bit_cast(unsigned, o);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // upper half of d[2h] <-> lower half of d[2h+1]
+                const auto x0 = __builtin_amdgcn_permlane32_swap(d[2 * h][0], d[2 * h + 1][0], false, false);
+                const auto x1 = __builtin_amdgcn_permlane32_swap(d[2 * h][1], d[2 * h + 1][1], false, false);
+                pend[i][h] = i32x4{(int)x0[0], (int)x1[0], (int)x0[1], (int)x1[1]};
+            }
+            const int g = pixel_of(ub + 256 * s + 64 * mq + 32 * i + li);
+            pend_off[i] = g < 0 ? kOob : g * 128 + (32 * nf + 8 * lh) * 2;
+        }
+        relbase = relbase + 256 >= kRing ? relbase + 256 - kRing : relbase + 256;
+        if (s < 2) stamp(p.stamps, 3 + 3 * s);
+    }
+    stamp(p.stamps, 10);
+    flush();
+    if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(p.stamps, 11);
+    }
+}
+
 }  // namespace
 
 int rn_conv_wide_count(void) { return kNumTiles; }
@@ -480,4 +720,30 @@ void rn_conv_wide_launch(rn_ctx *ctx, GemmParams &p, int which, bool dual)
     case 3: launch<256, 64, 8, 1>(ctx, p, dual); break;
     default: launch<224, 256, 1, 8>(ctx, p, dual); break;
     }
+}
+
+// ---- strip kernel: host side ----
+
+bool rn_conv_strip_eligible(const GemmParams &p)
+{
+    return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cs == 64 && p.Cout == 64 &&
+           p.cseg == 1 && p.chunk_dw == 0 && p.kreal == 0 && p.tap_rows == 1 && p.residual == nullptr &&
+           p.Ho == p.H && p.Wo == p.W && p.W + 3 <= kStripMargin && p.Ktot == 576 &&
+           (uint64_t)(p.M / (p.H * p.W) * (p.H + 1) + 1) * (uint64_t)(p.W + 2) < (1ull << 30);
+}
+
+void rn_conv_strip_launch(rn_ctx *ctx, const GemmParams &g)
+{
+    StripParams p;
+    p.in = g.in, p.w = g.w, p.out = g.out, p.scale = g.scale, p.shift = g.shift, p.relu = g.relu;
+    p.H = g.H, p.W = g.W, p.B = g.M / (g.H * g.W);
+    p.Wp = p.W + 2, p.Hq = p.H + 1;
+    rn_fast_div((unsigned)p.Wp, &p.mul_wp, &p.shr_wp);
+    rn_fast_div((unsigned)p.Hq, &p.mul_hq, &p.shr_hq);
+    p.U = (p.B * p.Hq + 1) * p.Wp;
+    p.nsteps = (p.U + 255) / 256;
+    p.in_bytes = g.in_bytes, p.out_bytes = g.out_bytes;
+    p.stamps = g.stamps;
+    const int blocks = p.nsteps < 256 ? p.nsteps : 256;  // one block per CU
+    conv_strip_kernel<<<dim3(blocks), dim3(512), 0, ctx->stream>>>(p);
 }

@@ -206,7 +206,7 @@ int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate)
     return RN_OK;
 }
 
-int rn_conv_tile_candidates(void) { return 8 + rn_conv_wide_count(); }
+int rn_conv_tile_candidates(void) { return 8 + rn_conv_wide_count() + 1; }  // + the strip kernel
 
 // library-internal (rn_model.c is plain C and sees the context only through functions)
 int rn_ctx_graphs_live(const rn_ctx *ctx) { return ctx ? ctx->graphs_live : 0; }

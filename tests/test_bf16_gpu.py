@@ -151,6 +151,80 @@ def test_wide_kernel_race_screen_at_full_size():
             lib.rn_ctx_set_conv_tile(ctx.handle, 0)
 
 
+STRIP_CASES = [(3, 20, 20), (1, 6, 6), (2, 56, 56), (5, 7, 61), (4, 1, 9), (2, 33, 5), (37, 28, 28)]
+
+
+@pytest.mark.parametrize("case", STRIP_CASES)
+def test_strip_kernel_matches_oracle_and_the_tile_kernels_bits(case):
+    """conv_strip_kernel (3x3 / stride 1 / 64 -> 64 channels: weights in registers, the zero-padded
+    image in a rolling LDS ring, operands swapped, stores straight from registers) -- the candidate
+    after the wide tiles.  Against the oracle on bf16-rounded operands and bit for bit against a
+    4-wave tile: widest image the ring margin allows (61), one-row and narrow images, several
+    images per step and several steps per block (37 x 28 x 28: 479 steps on 256 blocks)."""
+    from resnet_c_amd import _lib as L
+    B, H, W = case
+    x, w = rnd((B, 64, H, W), 900 + sum(case)), rnd((64, 64, 3, 3), 901 + sum(case)) / 24.0
+    g = np.random.default_rng(902 + sum(case))
+    sc, sh = g.random(64, dtype=np.float32) + 0.5, g.standard_normal(64, dtype=np.float32)
+    ctx, lib = R.get_ctx(), L.lib()
+    strip = lib.rn_conv_tile_candidates()
+    try:
+        lib.rn_ctx_set_conv_tile(ctx.handle, 4)
+        want_ep = ops.conv2d_nhwc_bf16(x, w, 1, 1, sc, sh, None, True)
+        want_plain = ops.conv2d_nhwc_bf16(x, w, 1, 1, out_f32=False)
+        lib.rn_ctx_set_conv_tile(ctx.handle, strip)
+        got_ep = ops.conv2d_nhwc_bf16(x, w, 1, 1, sc, sh, None, True)
+        got_plain = ops.conv2d_nhwc_bf16(x, w, 1, 1, out_f32=False)
+    finally:
+        lib.rn_ctx_set_conv_tile(ctx.handle, 0)
+    assert np.array_equal(got_ep, want_ep) and np.array_equal(got_plain, want_plain)
+    if B * H * W <= 8000:
+        y = O.conv2d(ops.bf16_round(x), ops.bf16_round(w), 1, 1)
+        want = np.maximum(y * sc[None, :, None, None] + sh[None, :, None, None], 0)
+        assert np.abs(got_ep - want).max() <= 2 ** -8 * np.abs(want).max() + 1e-5
+
+
+def test_strip_kernel_full_size_under_load():
+    """B = 256 at 56 x 56: 3,307 steps, 13 per block -- the ring wraps and every slot is rewritten
+    several times while the neighbours are still being read.  Many back-to-back runs against the
+    4-wave kernel's bits (a read that slipped ahead of its DMA would come and go with timing)."""
+    from resnet_c_amd import _lib as L
+    from resnet_c_amd.tensor import _DeviceBuffer
+    ctx, lib = R.get_ctx(), L.lib()
+    B, H, W, C = 256, 56, 56, 64
+    g = np.random.default_rng(77)
+    n_in, n_w = B * H * W * C, C * 9 * C
+    x, w, out = _DeviceBuffer(ctx, n_in * 2), _DeviceBuffer(ctx, n_w * 2), _DeviceBuffer(ctx, n_in * 2)
+    xh = ops.to_bf16_bits(g.standard_normal(n_in, dtype=np.float32))
+    wh = ops.to_bf16_bits(g.standard_normal(n_w, dtype=np.float32) / 24.0)
+    L.check(lib.rn_memcpy_h2d(ctx.handle, x.ptr, xh.ctypes.data, xh.nbytes), "h2d", ctx.handle)
+    L.check(lib.rn_memcpy_h2d(ctx.handle, w.ptr, wh.ctypes.data, wh.nbytes), "h2d", ctx.handle)
+    ep = L.Epilogue(None, None, None, 1)
+
+    def run(cand):
+        lib.rn_ctx_set_conv_tile(ctx.handle, cand)
+        L.check(lib.rn_conv2d_nhwc_forward_dt(ctx.handle, L.RN_DTYPE_BF16, L.RN_DTYPE_BF16, x.ptr, out.ptr, w.ptr,
+                                              3, 1, 1, H, W, B, C, C, H, W, ctypes.byref(ep)), "conv", ctx.handle)
+
+    def fetch():
+        ctx.sync()
+        h = np.empty(n_in, dtype=np.uint16)
+        L.check(lib.rn_memcpy_d2h(ctx.handle, h.ctypes.data, out.ptr, h.nbytes), "d2h", ctx.handle)
+        return h
+
+    try:
+        run(6)
+        want = fetch()
+        assert want.any()
+        L.check(lib.rn_memset(ctx.handle, out.ptr, 0xFF, n_in * 2), "memset", ctx.handle)
+        for rep in range(8):
+            for _ in range(5):
+                run(lib.rn_conv_tile_candidates())
+            assert np.array_equal(fetch(), want), rep
+    finally:
+        lib.rn_ctx_set_conv_tile(ctx.handle, 0)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_wide_kernel_random_shapes_against_the_4_wave_kernel(seed):
     """Random geometry (image size, stride, padding, channel counts that leave ragged M and N
@@ -170,7 +244,7 @@ def test_wide_kernel_random_shapes_against_the_4_wave_kernel(seed):
     try:
         lib.rn_ctx_set_conv_tile(ctx.handle, 4)
         want = ops.conv2d_nhwc_bf16(x, w, s, p, sc, sh, res, True)
-        for cand in (9, 10, 11, 12):
+        for cand in range(9, lib.rn_conv_tile_candidates() + 1):
             lib.rn_ctx_set_conv_tile(ctx.handle, cand)
             assert np.array_equal(ops.conv2d_nhwc_bf16(x, w, s, p, sc, sh, res, True), want), (cand, B, H, W, Cin, Cout, k, s, p)
     finally:

@@ -17,6 +17,7 @@ ap.add_argument("--cand", type=int, default=1)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--residual", action="store_true")
 ap.add_argument("--exact", action="store_true", help="small-Cin exact-K form (fp32): dims are the unpadded image")
+ap.add_argument("--raw", action="store_true", help="median of every stamp slot relative to slot 0")
 ap.add_argument("--soak", type=float, default=1.5, help="seconds of back-to-back launches before the stamped one")
 a = ap.parse_args()
 B, H, W, Cin, Cout, k, s, p = a.dims
@@ -60,6 +61,16 @@ lib.rn_ctx_set_debug_stamps(ctx.handle, None)
 raw = np.empty(nblk * 16, dtype=np.uint64)
 lib.rn_memcpy_d2h(ctx.handle, raw.ctypes.data, st.ptr, raw.nbytes)
 full = raw.reshape(nblk, 16).astype(np.float64)
+if a.raw:
+    full = full[full[:, 0] > 0]
+    print(f"blocks {len(full)}  span {(full.max() - full[:, 0].min()) / 100:.1f} us")
+    for i in range(16):
+        col = full[:, i]
+        ok = col > 0
+        if ok.any():
+            rel = (col[ok] - full[ok, 0]) / 100
+            print(f"  slot {i:2d}: median {np.median(rel):8.2f} us   p10 {np.percentile(rel, 10):8.2f}   p90 {np.percentile(rel, 90):8.2f}   blocks {ok.sum()}")
+    sys.exit(0)
 t = full[:, :5]
 keep = t[:, 0] > 0
 full = full[keep]
