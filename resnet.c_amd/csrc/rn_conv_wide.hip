@@ -580,21 +580,26 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(const StripParams p)
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) pend[i][h] = i32x4{0, 0, 0, 0};
-    auto flush = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[i][h]), rsrc_o,
-                                                       pend_off[i] == kOob ? kOob : pend_off[i] + 32 * h, 0, 0);
+    // the four 16-byte stores of a step's results: store q = 2i + h
+    auto store_piece = [&](int q) {
+        const int i = q >> 1, h = q & 1;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[i][h]), rsrc_o,
+                                               pend_off[i] == kOob ? kOob : pend_off[i] + 32 * h, 0, 0);
     };
 
+    // diagnostic stamps of step 4 (top, own memory landed, barrier passed, taps done, results packed)
+    // and of step 5's end, kept in registers and written when the block is done: a stamp stored
+    // inside the loop would be waited for by the next s_waitcnt vmcnt(0)
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
     int relbase = 0;  // (256 * s) mod 640
     for (int s = 0; s < nst; ++s) {
         // this wave's pieces of step s have landed, its reads of step s-1 are back; then all meet
+        if (s == 4) tk[0] = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (s == 4) tk[1] = wall_clock64();
         wait_and_barrier<0>();
-        if (s < 3) stamp(p.stamps, 1 + 3 * s);
-        flush();  // step s-1's results (nothing at s == 0)
+        if (s == 4) tk[2] = wall_clock64();
+        if (s == 0) stamp(p.stamps, 1);
 
         // next step's 256 positions: four pieces per wave, issued between the taps below
         int nxt_off[4];
@@ -608,11 +613,6 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(const StripParams p)
             nxt_off[j] = s + 1 < nst ? src_off(u, slot0 + prow) : kOob;
             nxt_dst[j] = lds_base + (unsigned)(slot0 * 128);
         }
-        // issued before the multiplication, not inside it: a piece needs a memory round trip
-        // (1.3 us was spent waiting at the barrier when the last one left at 7/8 of the step)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(nxt_off[j], srd_in, 0, nxt_dst[j]);
-
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -648,8 +648,18 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(const StripParams p)
                                                                  acc[n & 1], 0, 0, 0);
             if (n + kDepth < 72) px[n % kDepth] = read(n + kDepth);
             __builtin_amdgcn_sched_barrier(0);  // keep the read where it is written, kDepth pairs ahead
+            // The step's eight vector-memory instructions -- four DMA pieces for the next step, four
+            // stores of the previous step's results (nothing at s == 0) -- one every eight MFMAs.
+            // Issued together at the top of the step, the 64 of a block queued in front of the
+            // CU's one address unit and the waves started their MFMAs up to 1.5 us apart.
+            if ((n & 7) == 1) {
+                if (n < 32)
+                    dma16(nxt_off[n >> 3], srd_in, 0, (unsigned)__builtin_amdgcn_readfirstlane((int)nxt_dst[n >> 3]));
+                else if (n < 64)
+                    store_piece((n >> 3) - 4);
+            }
         }
-        if (s < 2) stamp(p.stamps, 2 + 3 * s);
+        if (s == 4) tk[3] = wall_clock64();
 
         // results: lane (li, lh) holds channels 32nf + 8j + 4lh + {0..3}, j = 0..3, of pixel li of
         // each fragment.  Affine + ReLU, bf16, then the half-waves trade 4-channel groups so that
@@ -683,13 +693,17 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(const StripParams p)
             pend_off[i] = g < 0 ? kOob : g * 128 + (32 * nf + 8 * lh) * 2;
         }
         relbase = relbase + 256 >= kRing ? relbase + 256 - kRing : relbase + 256;
-        if (s < 2) stamp(p.stamps, 3 + 3 * s);
+        if (s == 4) tk[4] = wall_clock64();
+        if (s == 5) tk[5] = wall_clock64();
     }
     stamp(p.stamps, 10);
-    flush();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_piece(q);
     if (p.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(p.stamps, 11);
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 6; ++i) p.stamps[(size_t)blockIdx.x * 16 + 2 + i] = tk[i];
     }
 }
 
