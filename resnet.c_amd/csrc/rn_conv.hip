@@ -577,7 +577,41 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
                                : static_cast<char *>(p.out) + (long long)ks_idx * p.split_stride;
     const __amdgpu_buffer_rsrc_t rsrc_o =
         __builtin_amdgcn_make_buffer_rsrc(out_base, 0, p.out_bytes, 0x00020000);
-    if (vec) {
+    if (sizeof(TO) == 4 && p.out_nchw && !raw) {
+        // NCHW output (drop-in route): lanes along the channels -- conflict-free column reads of
+        // the staged tile -- and four consecutive pixels of one channel per 16-byte store.  The
+        // stores of a wave scatter over 64 channel planes; consecutive steps of a lane continue
+        // its plane, so L2 sees whole lines, and against a separate transpose launch (a read and
+        // a write of the whole tensor) the address unit's time is cheap.
+        const int c = t % BN, nn = n0 + c;
+        const bool ch_ok = nn < p.Cout;
+        const float scl = (has_scale && ch_ok) ? p.scale[nn] : 1.f;
+        const float shf = (has_shift && ch_ok) ? p.shift[nn] : -0.f;
+        for (int q = t / BN; q < BM / 4; q += 256 / BN) {
+            const int m = m0 + 4 * q;
+            if (!ch_ok || m >= p.M) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = fmaf(Cs[(4 * q + j) * BN + c], scl, shf);
+                v[j] = p.relu ? fmaxf(y, 0.f) : y;
+            }
+            const int b = (int)(__umulhi((unsigned)m, p.mul_hw) >> p.shr_hw), hw = m - b * p.HoWo;
+            if (m + 3 < p.M && hw + 3 < p.HoWo) {
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = __float_as_uint(v[j]);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_o, ((b * p.Cout + nn) * p.HoWo + hw) * 4, 0, 0);
+            } else {
+                for (int j = 0; j < 4 && m + j < p.M; ++j) {
+                    const int mj = m + j;
+                    const int bj = (int)(__umulhi((unsigned)mj, p.mul_hw) >> p.shr_hw);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), rsrc_o,
+                                                          ((bj * p.Cout + nn) * p.HoWo + mj - bj * p.HoWo) * 4, 0, 0);
+                }
+            }
+        }
+    } else if (vec) {
         // straight-line: 16-byte LDS read, channel affine, residual, ReLU, 16-byte store per pass
         float sc[EPT], sh[EPT];
 #pragma unroll
@@ -814,11 +848,13 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
                 uint64_t k, uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out,
                 uint64_t B, uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W,
                 const rn_epilogue *ep, const char *what, const rn_conv_second *second = nullptr,
-                bool exact = false)
+                bool exact = false, bool out_nchw = false)
 {
     const int es = dt_in == RN_DTYPE_BF16 ? 2 : 4;
     const int bke = 128 / es;
     GemmParams p;
+    // NCHW output: fp32, no residual (it would be NHWC); a 1x1 output image is the same in both
+    p.out_nchw = out_nchw && dt_out == RN_DTYPE_F32 && !(ep && ep->residual) && h_out * w_out > 1;
     p.in = inp;
     p.w = packed;
     p.out = out;
@@ -990,7 +1026,7 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     // K loop over several blocks; each writes a raw fp32 partial tile to scratch and a second
     // kernel adds the partials in split order and applies the epilogue.  Deterministic, but
     // the summation order differs from the unsplit launch, so it is opt-in.
-    if (ctx->split_k > 1 && total < 512 && p.nk >= 8 && Cout % 4 == 0 &&
+    if (ctx->split_k > 1 && total < 512 && p.nk >= 8 && Cout % 4 == 0 && !p.out_nchw &&
         !(second && dt_in == RN_DTYPE_BF16)) {
         int S = (int)rn_ceil_div(1024, total);
         if (S > ctx->split_k) S = ctx->split_k;
@@ -1051,7 +1087,9 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
         // blocks, in the same summation order as any other batch size)
         unsigned tail = total > 256 ? (unsigned)(total % 256) : (unsigned)total;
         tail -= tail % (unsigned)tiles_n;
-        const bool cut = ctx->split_k <= 1 && tail > 0 &&
+        // (NCHW output: the finishing kernel writes NHWC, so the tail tiles fold their chunks in
+        // registers like the others -- the same sum)
+        const bool cut = ctx->split_k <= 1 && tail > 0 && !p.out_nchw &&
                          rn_ceil_div((uint64_t)tail * S, 256) < (uint64_t)S;
         // the workspace holds only the tail rows [row0, M) of every chunk slice; the kernel
         // addresses it like the output, through a base moved back by row0 rows
@@ -1237,20 +1275,18 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
                            padding, h_out, w_out, B, in_channels, out_channels, H, W, nullptr,
                            "rn_conv2d_forward(nhwc)");
     }
-    // NCHW caller: transpose in, contract, transpose out
+    // NCHW caller: transpose in, contract; the contraction's epilogue writes NCHW itself
     const uint64_t cs = rn_conv2d_input_channels(in_channels);
-    void *xin = nullptr, *xout = nullptr;
+    void *xin = nullptr;
     RN_TRY(rn_scratch(ctx, 2, B * H * W * cs * sizeof(float), &xin));
-    RN_TRY(rn_scratch(ctx, 3, B * h_out * w_out * out_channels * sizeof(float), &xout));
     if (cs != in_channels) {
         RN_TRY(rn_nchw_to_nhwc_pad(ctx, inp, (float *)xin, B, in_channels, H, W, cs));
     } else {
         RN_TRY(rn_nchw_to_nhwc(ctx, inp, (float *)xin, B, in_channels, H, W));
     }
-    RN_TRY(launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, xin, xout, wp, kernel_size, stride, padding,
+    return launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, xin, out, wp, kernel_size, stride, padding,
                        h_out, w_out, B, in_channels, out_channels, H, W, nullptr,
-                       "rn_conv2d_forward(gemm)"));
-    return rn_nhwc_to_nchw(ctx, (const float *)xout, out, B, out_channels, h_out, w_out);
+                       "rn_conv2d_forward(gemm)", nullptr, false, true);
 }
 
 int rn_conv2d_nhwc_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const void *inp, void *out,

@@ -63,6 +63,9 @@ struct GemmParams {
     // the row's first element (kc = KW*Cin, kskip = (W - KW)*Cin), zero weight past kreal
     int kc, kskip, kreal;
     unsigned mul_kc, shr_kc;
+    // fp32 output written as NCHW instead of NHWC (the literal drop-in route, rn_conv2d_forward
+    // on NCHW tensors): saves the transpose launch behind the contraction
+    int out_nchw;
     // diagnostic only (tools/conv_stamps.py): 16 stamp slots per block, or null
     unsigned long long *stamps;
 };
