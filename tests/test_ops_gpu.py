@@ -565,6 +565,26 @@ def test_one_thread_two_contexts_interleaved():
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("case", [(3, 32, 64, 14, 14, 3, 1, 1),      # plain
+                                  (5, 64, 72, 7, 7, 1, 1, 0),        # 49 pixels per image: quads straddle images, unaligned planes
+                                  (2, 128, 40, 9, 11, 3, 2, 1),      # K = 1152: chunked K sum, ragged channels
+                                  (1, 3, 64, 32, 32, 7, 2, 3),       # small-Cin stem form
+                                  (40, 128, 64, 7, 7, 3, 1, 1)])     # chunked, more than one round of tiles: a tail that the NHWC route cuts
+def test_nchw_route_writes_the_nhwc_routes_bits(case):
+    """rn_conv2d_forward on NCHW tensors transposes its input and lets the contraction's epilogue
+    write NCHW itself (GemmParams::out_nchw).  Same products and the same summation order as the
+    NHWC call -- also where the NHWC launch cuts its tail tiles into K chunks and a finishing
+    kernel adds them -- so the two layouts must agree bit for bit, and with the oracle."""
+    B, Cin, Cout, H, W, k, s, p = case
+    x, w = rnd((B, Cin, H, W), 300 + sum(case)), rnd((Cout, Cin, k, k), 301 + sum(case)) / np.sqrt(Cin * k * k)
+    a = ops.conv2d(x, w, s, p, "nchw")
+    if Cin >= 4:   # (an NHWC call with fewer than four channels takes the direct kernel: another order)
+        assert np.array_equal(a, ops.conv2d(x, w, s, p, "nhwc"))
+    if B * H * W <= 4000:
+        want = O.conv2d(x, w, s, p)
+        assert np.abs(a - want).max() <= 2e-6 * np.sqrt(Cin * k * k) * float(np.abs(want).max()) + 1e-6
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 32, 32), (1, 3, 40, 48), (2, 2, 26, 16)])
 @pytest.mark.parametrize("bf16", [False, True])
 def test_fused_stem_and_maxpool_match_the_four_reference_ops(shape, bf16):
