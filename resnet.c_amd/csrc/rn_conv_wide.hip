@@ -500,7 +500,7 @@ constexpr int kStripMargin = 64;  // ring position of a block's first output pos
 __global__ __launch_bounds__(512, 2) void conv_strip_kernel(const StripParams p)
 {
     // ring | scale[64], shift[64] | the weights as they lie in memory (start-up only)
-    __shared__ __attribute__((aligned(16))) char lds[kRing * 128 + 512 + 64 * 576 * 2];
+    __shared__ __attribute__((aligned(16))) char lds[kRing * 128 + 512 + 73 * 1024];
     stamp(p.stamps, 0);
     float *const ssl = reinterpret_cast<float *>(lds + kRing * 128);
     const int t = threadIdx.x, lane = t & 63;
@@ -530,16 +530,23 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(const StripParams p)
     const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     const unsigned lds_base = (unsigned)(uintptr_t)((lds_void *)lds);
 
-    // Weights: 72 KB, the same for every block.  Fetched as they lie in memory (72 coalesced
-    // 1-KiB DMA pieces) and picked out of LDS -- a lane's 36 fragments are 16 bytes of 36 places
-    // in one 1,152-byte row, and 32 rows per wave instruction straight from global cost the
-    // start of every block 8 us of address-coalescer time.
+    // Weights: 72 KB, the same for every block.  Fetched coalesced (1-KiB DMA pieces) and picked
+    // out of LDS -- a lane's 36 fragments are 16 bytes of 36 places in one 1,152-byte row, and 32
+    // rows per wave instruction straight from global cost the start of every block 8 us of
+    // address-coalescer time.  The LDS rows are 73 chunks long, not 72: with 72 the rows of a
+    // ds_read_b128 lane group start on two bank offsets only (8-way conflict, PMC: 19 % of the
+    // kernel's LDS cycles); 9r mod 16 is different for all 16 rows of a group.
     {
         const i32x4 srd_w = make_srd(p.w, 64 * 576 * 2);
 #pragma unroll
-        for (int j = 0; j < 9; ++j)
-            dma16(lane * 16, srd_w, (8 * j + wave) * 1024,
+        for (int j = 0; j < 10; ++j) {
+            if (8 * j + wave >= 73) break;               // 64 rows x 73 chunks = 73 pieces (wave-uniform)
+            const int pos = (8 * j + wave) * 64 + lane;  // 16-byte chunk of the LDS image
+            const int r = (pos * 7183) >> 19;            // pos / 73 for pos < 4,736
+            const int c = pos - r * 73;
+            dma16(c < 72 ? (r * 72 + c) * 16 : kOob, srd_w, 0,
                   lds_base + (unsigned)(kRing * 128 + 512 + (8 * j + wave) * 1024));
+        }
     }
 
     // padded position u -> pixel index of the NHWC tensor, or -1 for a padding position
@@ -569,7 +576,7 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(const StripParams p)
     i32x4 wreg[36];
     {
         wait_and_barrier<0>();
-        const char *wrow = lds + kRing * 128 + 512 + (32 * nf + li) * (576 * 2) + lh * 16;
+        const char *wrow = lds + kRing * 128 + 512 + (32 * nf + li) * (73 * 16) + lh * 16;
 #pragma unroll
         for (int s = 0; s < 36; ++s) wreg[s] = *reinterpret_cast<const i32x4 *>(wrow + s * 32);
     }

@@ -21,8 +21,11 @@ def main():
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
             short = name.split("(")[0][-60:] if len(name) > 60 else name
-            if "conv_gemm_kernel" in name:
-                short = "conv_gemm_kernel" + name.split("conv_gemm_kernel")[1].split(">")[0] + ">"
+            for fam in ("conv_gemm_kernel", "conv_wide_kernel", "stem_pool_kernel"):
+                if fam in name:
+                    short = fam + name.split(fam)[1].split(">")[0] + ">"
+            if "conv_strip_kernel" in name:
+                short = "conv_strip_kernel"
             agg[short][r["Counter_Name"]] += float(r["Counter_Value"])
             key = (f, r["Dispatch_Id"])
             if key not in seen:
