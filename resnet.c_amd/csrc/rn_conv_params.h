@@ -1,5 +1,6 @@
 // Parameters and small types shared by the contraction kernels (rn_conv.hip: the 4-wave
-// kernels for fp32 and bf16; rn_conv_wide.hip: the 8-wave LDS-DMA kernel for bf16).
+// kernels for fp32 and bf16; rn_conv_wide.hip: the 8-wave LDS-DMA kernels for bf16 -- 256-wide
+// tiles and the strip kernel).
 #ifndef RN_CONV_PARAMS_H
 #define RN_CONV_PARAMS_H
 
@@ -104,7 +105,7 @@ inline void rn_fast_div(unsigned d, unsigned *mul, unsigned *shr)
 }
 
 // bf16 contraction on 256-wide block tiles (rn_conv_wide.hip).  which: 0 = 256x256, 1 = 256x128,
-// 2 = 128x256, 3 = 256x64.  Caller has checked rn_conv_wide_eligible().
+// 2 = 128x256, 3 = 256x64, 4 = 224x256.  Caller has checked rn_conv_wide_eligible().
 int rn_conv_wide_count(void);
 bool rn_conv_wide_eligible(const rn_gemm::GemmParams &p, int which);
 void rn_conv_wide_tile(int which, int *bm, int *bn);

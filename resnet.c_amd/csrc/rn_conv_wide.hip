@@ -28,6 +28,9 @@
 //
 // Roofline: MFMA for K >= ~512 and N >= 128 (the 3x3 convolutions, conv1 of layer3/4, the fused
 // conv3 + downsample pairs); short-K layers stay on the 4-wave kernel (rn_model_tune decides).
+//
+// Second kernel of this file (same DMA helpers): conv_strip_kernel for the 3x3 / 64 -> 64 layers,
+// described where it starts.
 #include <type_traits>
 
 #include "rn_conv_params.h"
