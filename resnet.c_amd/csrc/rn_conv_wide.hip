@@ -311,6 +311,34 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
     };
     using AllPieces = std::integral_constant<int, PA + PB>;
 
+    constexpr int EPT = Out<TO>::EPT;
+    constexpr int CV = BN / EPT, RPP = 512 / CV, STEPS = EROWS / RPP;
+    static_assert(STEPS >= 1 && EROWS % RPP == 0, "epilogue geometry");
+    const int cv = t % CV, rr = t / CV;
+    const int n = n0 + cv * EPT;
+    const bool col_ok = n < p.Cout;  // Cout % 8 == 0 (eligibility): then n + 8 <= Cout
+    const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
+    const bool has_res = p.residual != nullptr;
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
+        has_res ? const_cast<void *>(p.residual) : p.out, 0, has_res ? p.out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(
+        has_scale ? (void *)const_cast<float *>(p.scale) : p.out, 0, has_scale ? p.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_sh = __builtin_amdgcn_make_buffer_rsrc(
+        has_shift ? (void *)const_cast<float *>(p.shift) : p.out, 0, has_shift ? p.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    // residual rows of a pass.  (Asking for the first pass's while the last K tile is multiplied
+    // was measured: the K loop's closing vmcnt(0) then waits for them, +1.4 us, and the epilogue
+    // gets no shorter -- with a residual it is bound by its vector arithmetic, not by that load.)
+    i32x4 resv[STEPS];
+    auto load_res = [&](int row0) {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int m = m0 + row0 + rr + s * RPP;
+            const int off = (col_ok && m < p.M && row0 + rr + s * RPP < BM) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
+            resv[s] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, off, 0, 0));
+        }
+    };
+
     // ---- K loop ----------------------------------------------------------------------------
     // issue order is what the counted waits rely on:
     //   SB == 3:  prologue A0 B0 A1 B1; step t issues A(t+2) B(t+2);  wait leaves A(t+1) B(t+1)
@@ -361,21 +389,6 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
     // C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5); one
     // ds_write_b32 per register puts 32 consecutive columns of two rows, conflict-free.  Then
     // 16 bytes of one output row per thread and step: channel affine, residual, ReLU, store.
-    constexpr int EPT = Out<TO>::EPT;
-    constexpr int CV = BN / EPT, RPP = 512 / CV, STEPS = EROWS / RPP;
-    static_assert(STEPS >= 1 && EROWS % RPP == 0, "epilogue geometry");
-    const int cv = t % CV, rr = t / CV;
-    const int n = n0 + cv * EPT;
-    const bool col_ok = n < p.Cout;  // Cout % 8 == 0 (eligibility): then n + 8 <= Cout
-    const bool has_scale = p.scale != nullptr, has_shift = p.shift != nullptr;
-    const bool has_res = p.residual != nullptr;
-    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
-        has_res ? const_cast<void *>(p.residual) : p.out, 0, has_res ? p.out_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(
-        has_scale ? (void *)const_cast<float *>(p.scale) : p.out, 0, has_scale ? p.Cout * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_sh = __builtin_amdgcn_make_buffer_rsrc(
-        has_shift ? (void *)const_cast<float *>(p.shift) : p.out, 0, has_shift ? p.Cout * 4 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
     float sc[EPT], sh[EPT];
 #pragma unroll
     for (int j4 = 0; j4 < EPT / 4; ++j4) {
@@ -390,16 +403,13 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
         }
     }
     float *const Cs = reinterpret_cast<float *>(lds);  // [EROWS][BN] fp32
-#pragma unroll
-    for (int pass = 0; pass < CPASS; ++pass) {
-        const int row0 = pass * EROWS;  // first tile row of this pass
-        i32x4 resv[STEPS];
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const int m = m0 + row0 + rr + s * RPP;
-            const int off = (col_ok && m < p.M && row0 + rr + s * RPP < BM) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
-            resv[s] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, off, 0, 0));
-        }
+    // The read-back half, specialised on the two launch-uniform switches: without a residual there
+    // are no residual loads, unpacks, adds and selects, and a ReLU that is known needs no select --
+    // 20 instead of ~45 vector instructions per 8 outputs (two thirds of the network's launches
+    // have no residual, all have the ReLU).
+    auto read_back = [&](int row0, auto with_res, auto with_relu) {
+        constexpr bool RES = decltype(with_res)::value, RELU = decltype(with_relu)::value;
+        if constexpr (RES) load_res(row0);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int fr = wm * TM + mi * 32 - row0;  // fragment's first row in this pass: wave-uniform
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
             const int row = rr + s * RPP;
             const int m = m0 + row0 + row;
             float v[EPT], res[EPT];
-            Out<TO>::unpack(resv[s], res);
+            if constexpr (RES) Out<TO>::unpack(resv[s], res);
 #pragma unroll
             for (int j4 = 0; j4 < EPT / 4; ++j4) {
                 const float4 x = *reinterpret_cast<const float4 *>(Cs + row * BN + cv * EPT + 4 * j4);
@@ -426,11 +436,22 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
                 float y = fmaf(v[j], sc[j], sh[j]);
-                y = has_res ? y + res[j] : y;
-                v[j] = p.relu ? fmaxf(y, 0.f) : y;
+                if constexpr (RES) y = y + res[j];
+                v[j] = RELU ? fmaxf(y, 0.f) : y;
             }
             const int off = (col_ok && m < p.M && row0 + row < BM) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Out<TO>::pack(v)), rsrc_o, off, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int pass = 0; pass < CPASS; ++pass) {
+        const int row0 = pass * EROWS;  // first tile row of this pass
+        if (has_res) {
+            if (p.relu) read_back(row0, std::true_type{}, std::true_type{});
+            else read_back(row0, std::true_type{}, std::false_type{});
+        } else {
+            if (p.relu) read_back(row0, std::false_type{}, std::true_type{});
+            else read_back(row0, std::false_type{}, std::false_type{});
         }
         if (pass + 1 < CPASS) __syncthreads();
     }
