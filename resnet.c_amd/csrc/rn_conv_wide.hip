@@ -326,9 +326,10 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
     const __amdgpu_buffer_rsrc_t rsrc_sh = __builtin_amdgcn_make_buffer_rsrc(
         has_shift ? (void *)const_cast<float *>(p.shift) : p.out, 0, has_shift ? p.Cout * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
-    // residual rows of a pass.  (Asking for the first pass's while the last K tile is multiplied
-    // was measured: the K loop's closing vmcnt(0) then waits for them, +1.4 us, and the epilogue
-    // gets no shorter -- with a residual it is bound by its vector arithmetic, not by that load.)
+    // residual rows of a pass.  (Asking for the first pass's earlier -- during the last K tile, or
+    // before the K loop -- was measured on the K = 256 layers: the wait only moves, into the K
+    // loop's closing vmcnt(0) or into the first operand tiles' (+2.5 us there); those launches
+    // run at the memory system's pace, 3.9 TB/s.)
     i32x4 resv[STEPS];
     auto load_res = [&](int row0) {
 #pragma unroll
@@ -433,11 +434,15 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
                 const float4 x = *reinterpret_cast<const float4 *>(Cs + row * BN + cv * EPT + 4 * j4);
                 v[4 * j4] = x.x, v[4 * j4 + 1] = x.y, v[4 * j4 + 2] = x.z, v[4 * j4 + 3] = x.w;
             }
+            // two outputs per instruction: v_pk_fma_f32 / v_pk_add_f32 (the same IEEE results)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                float y = fmaf(v[j], sc[j], sh[j]);
-                if constexpr (RES) y = y + res[j];
-                v[j] = RELU ? fmaxf(y, 0.f) : y;
+            for (int j = 0; j < EPT; j += 2) {
+                f32x2 y = __builtin_elementwise_fma(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]},
+                                                    f32x2{sh[j], sh[j + 1]});
+                if constexpr (RES) y = y + f32x2{res[j], res[j + 1]};
+                v[j] = RELU ? fmaxf(y[0], 0.f) : y[0];
+                v[j + 1] = RELU ? fmaxf(y[1], 0.f) : y[1];
             }
             const int off = (col_ok && m < p.M && row0 + row < BM) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, Out<TO>::pack(v)), rsrc_o, off, 0, 0);
