@@ -612,7 +612,9 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
             }
         }
     } else if (vec) {
-        // straight-line: 16-byte LDS read, channel affine, residual, ReLU, 16-byte store per pass
+        // straight-line: 16-byte LDS read, channel affine, residual, ReLU, 16-byte store per pass.
+        // The two launch-uniform switches (residual, ReLU) pick one of four copies of the loop:
+        // as per-element selects they cost as many vector instructions as the arithmetic itself.
         float sc[EPT], sh[EPT];
 #pragma unroll
         for (int j4 = 0; j4 < EPT / 4; ++j4)
@@ -623,25 +625,40 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
                 sh[4 * j4 + j] = (has_shift && !raw) ? __uint_as_float(shv[j4][j]) : -0.f;
             }
         const bool col_ok = n < p.Cout;
+        auto rows_out = [&](auto with_res, auto with_relu) {
+            constexpr bool RES = decltype(with_res)::value, RELU = decltype(with_relu)::value;
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int row = rr + ps * RPP;
-            const int m = m0 + row;
-            float v[EPT], res[EPT];
-            OutVec<TO>::unpack(resv[ps], res);
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int row = rr + ps * RPP;
+                const int m = m0 + row;
+                float v[EPT], res[EPT];
+                if constexpr (RES) OutVec<TO>::unpack(resv[ps], res);
 #pragma unroll
-            for (int j4 = 0; j4 < EPT / 4; ++j4) {
-                const float4 x = *reinterpret_cast<const float4 *>(Cs + row * BN + cv * EPT + 4 * j4);
-                v[4 * j4] = x.x, v[4 * j4 + 1] = x.y, v[4 * j4 + 2] = x.z, v[4 * j4 + 3] = x.w;
+                for (int j4 = 0; j4 < EPT / 4; ++j4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(Cs + row * BN + cv * EPT + 4 * j4);
+                    v[4 * j4] = x.x, v[4 * j4 + 1] = x.y, v[4 * j4 + 2] = x.z, v[4 * j4 + 3] = x.w;
+                }
+                // two outputs per instruction: v_pk_fma_f32 / v_pk_add_f32 (the same IEEE results)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int j = 0; j < EPT; j += 2) {
+                    f32x2 y = __builtin_elementwise_fma(f32x2{v[j], v[j + 1]}, f32x2{sc[j], sc[j + 1]},
+                                                        f32x2{sh[j], sh[j + 1]});
+                    if constexpr (RES) y = y + f32x2{res[j], res[j + 1]};
+                    v[j] = RELU ? fmaxf(y[0], 0.f) : y[0];
+                    v[j + 1] = RELU ? fmaxf(y[1], 0.f) : y[1];
+                }
+                const int off = (col_ok && m < p.M) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
+                __builtin_amdgcn_raw_buffer_store_b128(OutVec<TO>::pack(v), rsrc_o, off, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                float y = fmaf(v[j], sc[j], sh[j]);
-                y = (has_res && !raw) ? y + res[j] : y;
-                v[j] = (p.relu && !raw) ? fmaxf(y, 0.f) : y;
-            }
-            const int off = (col_ok && m < p.M) ? (m * p.Cout + n) * (int)sizeof(TO) : kOob;
-            __builtin_amdgcn_raw_buffer_store_b128(OutVec<TO>::pack(v), rsrc_o, off, 0, 0);
+        };
+        const bool do_res = has_res && !raw, do_relu = p.relu && !raw;
+        if (do_res) {
+            if (do_relu) rows_out(std::true_type{}, std::true_type{});
+            else rows_out(std::true_type{}, std::false_type{});
+        } else {
+            if (do_relu) rows_out(std::false_type{}, std::true_type{});
+            else rows_out(std::false_type{}, std::false_type{});
         }
     } else if (n < p.Cout) {
         // ragged channel count (Cout % EPT != 0): element-wise, rare
