@@ -96,6 +96,8 @@ struct rn_model {
     int pair_fusion;  /* fused mode: conv3 + downsample as one contraction (default on) */
     int stem_exact;   /* fp32: stem in the exact-K form, K = 160 instead of 224 (default on) */
     float *stem_packed_exact;
+    int chain;               /* fused bf16 mode: conv3 of a 64-channel block + conv1 of the next block as one launch (default on) */
+    int t1_ready;            /* the previous block's chained launch has produced this block's conv1 output */
     int stem_pool;           /* fused mode: stem + batch-norm + ReLU + max-pool as one launch (default on) */
     void *stem_pool_packed;  /* its weight panel, model dtype */
     void *fc_packed;  /* fc.weight in the model dtype (bf16 models only) */
@@ -186,6 +188,7 @@ int rn_model_create(rn_ctx *ctx, rn_model **out, int arch)
     if (m) m->pair_fusion = m->stem_exact = 1;
     if (m) m->streams = 1;
     if (m) m->stem_pool = 1;
+    if (m) m->chain = 1;
     if (m) m->front_parts = 1;
     if (!m) return RN_ERR_NOMEM;
     m->ctx = ctx;
@@ -544,6 +547,13 @@ int rn_model_set_stem_pool_fusion(rn_model *m, int on)
     return RN_OK;
 }
 
+int rn_model_set_chain(rn_model *m, int on)
+{
+    if (!m) return RN_ERR_INVALID;
+    m->chain = on ? 1 : 0;
+    return RN_OK;
+}
+
 int rn_model_set_front_parts(rn_model *m, int parts)
 {
     if (!m || parts < 1 || parts > 16 || (parts & (parts - 1))) return RN_ERR_INVALID;
@@ -732,6 +742,42 @@ static int op_pair(rn_model *m, rn_block *b, const void *t, const void *x, void 
     return prof_end(m);
 }
 
+/* conv3 + bn3 + residual + ReLU of block b and conv1 + bn1 + ReLU of the block after it as one
+ * launch (rn_conv_chain_forward_dt): t2 -> y (written: the next block's residual) -> the next
+ * block's t1, y reaching conv1 through LDS.  Algorithmic work: both contractions' FLOPs; bytes
+ * t2 + residual + y + t1 + both weight panels (y is not read back). */
+static int chain_applies(const rn_model *m, const rn_block *b, int mode)
+{
+    const int bi = (int)(b - m->blocks);
+    const rn_conv *c3 = &m->convs[b->conv3], *n1;
+    if (!m->chain || mode != RN_FWD_FUSED || m->dtype != RN_DTYPE_BF16 || m->recording) return 0;
+    if (b->ds >= 0 && m->pair_fusion) return 0; /* the pair has no residual operand: its own launch */
+    if (bi + 1 >= m->n_blocks) return 0;
+    if (m->front_parts > 1 && bi + 1 == m->depths[0]) return 0; /* the next block runs in another slice */
+    n1 = &m->convs[m->blocks[bi + 1].conv1];
+    return c3->k == 1 && c3->stride == 1 && c3->cin == 64 && c3->cout == 256 && n1->k == 1 &&
+           n1->stride == 1 && n1->cin == 256 && (n1->cout == 64 || n1->cout == 128);
+}
+
+static int op_chain(rn_model *m, const rn_block *b, const void *t2, const void *shortcut, void *y,
+                    uint64_t B, uint64_t H, uint64_t W)
+{
+    const rn_conv *c3 = &m->convs[b->conv3];
+    const rn_conv *n1 = &m->convs[m->blocks[(b - m->blocks) + 1].conv1];
+    const double M = (double)(B * H * W), es = (double)elem_size(m);
+    char name[RN_MAX_KEY];
+    snprintf(name, sizeof(name), "%.*s+next.conv1", (int)(RN_MAX_KEY - 12), c3->name);
+    TRY(prof_begin(m, "conv2d+epilogue+conv2d", name,
+                   2.0 * M * ((double)c3->cout * (double)c3->cin + (double)n1->cout * (double)n1->cin),
+                   es * (M * (double)(c3->cin + 2 * c3->cout + n1->cout) +
+                         (double)(c3->cout * c3->cin + n1->cout * n1->cin))));
+    TRY(rn_conv_chain_forward_dt(m->run, m->dtype, t2, shortcut, y, c3->packed, c3->scale, c3->shift,
+                                 m->v.t1, n1->packed, n1->scale, n1->shift, B * H * W, c3->cin,
+                                 c3->cout, n1->cout));
+    m->t1_ready = 1;
+    return prof_end(m);
+}
+
 static int op_bn(rn_model *m, const rn_conv *cv, float *y, uint64_t B, uint64_t HW)
 {
     const double n = (double)(B * cv->cout * HW);
@@ -798,12 +844,17 @@ static int block_forward(rn_model *m, rn_block *b, const float *x, float *y, uin
             shortcut = m->v.dsb;
         }
         ep.scale = c1->scale; ep.shift = c1->shift; ep.residual = NULL; ep.relu = 1;
-        TRY(op_conv(m, c1, x, m->v.t1, B, h, w, &ep, -1));
+        if (m->t1_ready)
+            m->t1_ready = 0; /* the block before has left this conv1's output in t1 (op_chain) */
+        else
+            TRY(op_conv(m, c1, x, m->v.t1, B, h, w, &ep, -1));
         ep.scale = c2->scale; ep.shift = c2->shift;
         TRY(op_conv(m, c2, m->v.t1, m->v.t2, B, h, w, &ep, -1));
         if (pair) {
             /* the downsample tensor is never materialised: its K rows ride in conv3's loop */
             TRY(op_pair(m, b, m->v.t2, x, y, B, ho, wo, h, w));
+        } else if (chain_applies(m, b, mode)) {
+            TRY(op_chain(m, b, m->v.t2, shortcut, y, B, ho, wo));
         } else {
             ep.scale = c3->scale; ep.shift = c3->shift; ep.residual = shortcut;
             TRY(op_conv(m, c3, m->v.t2, y, B, ho, wo, &ep, -1));
@@ -857,6 +908,7 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
         m->v.pooled = (float *)((char *)m->pooled + img_off * 2048 * es);
     }
     m->cur_mode = mode;
+    m->t1_ready = 0;
     saved_layout = rn_ctx_get_layout(m->run);
     rn_ctx_set_layout(m->run, RN_LAYOUT_NHWC);
     st = RN_OK;

@@ -273,6 +273,11 @@ class NativeModel:
     def streams(self) -> int:
         return int(L.lib().rn_model_get_streams(self.handle))
 
+    def set_chain(self, on: bool) -> None:
+        """Fused bf16 mode: conv3 of a 64-channel block + conv1 of the next block as one launch
+        (default on; the same bits either way)."""
+        L.check(L.lib().rn_model_set_chain(self.handle, int(on)), "rn_model_set_chain")
+
     def set_stem_pool_fusion(self, on) -> None:
         """Fused mode: conv1 + bn1 + relu + maxpool as one launch (default on); 2 = that launch
         reads the NCHW input itself, no layout launch in front of it."""

@@ -260,6 +260,41 @@ def conv2d_nhwc_bf16(x, w, stride=1, pad=0, scale=None, shift=None, residual=Non
     return y.reshape(B, ho, wo, Cout).transpose(0, 3, 1, 2).copy()
 
 
+def conv_chain_bf16(t2, x, w3, scale3, shift3, w1, scale1, shift1):
+    """rn_conv_chain_forward_dt: relu(bn3(conv1x1(t2, w3)) + x) -> y and relu(bn1(conv1x1(y, w1)))
+    -> t1 as one launch (bf16 storage).  NCHW fp32 host arrays in (rounded to bf16 on upload);
+    returns (y, t1) as NCHW fp32 host arrays."""
+    from .tensor import _DeviceBuffer
+    ctx, lib = get_ctx(), L.lib()
+    B, Cm, H, W = t2.shape
+    C, N1 = w3.shape[0], w1.shape[0]
+    rows = B * H * W
+
+    def up_act(a):
+        return _up_raw(to_bf16_bits(np.asarray(a, dtype=np.float32).transpose(0, 2, 3, 1)))
+
+    def pack(w, cin, cout):
+        dw = _up(w, "nchw")
+        pk = _DeviceBuffer(ctx, int(lib.rn_conv2d_packed_weight_numel_dt(L.RN_DTYPE_BF16, cin, cout, 1)) * 2)
+        L.check(lib.rn_conv2d_pack_weight_dt(ctx.handle, L.RN_DTYPE_BF16, dw.data(), pk.ptr, cin, cout, 1),
+                "pack_dt", ctx.handle)
+        return pk
+
+    dt2, dx = up_act(t2), up_act(x)
+    p3, p1 = pack(w3, Cm, C), pack(w1, C, N1)
+    keep = [_up(np.asarray(v, dtype=np.float32), "nchw") if v is not None else None
+            for v in (scale3, shift3, scale1, shift1)]
+    ptr = [k.data() if k else None for k in keep]
+    y, t1 = _DeviceBuffer(ctx, rows * C * 2), _DeviceBuffer(ctx, rows * N1 * 2)
+    L.check(lib.rn_conv_chain_forward_dt(ctx.handle, L.RN_DTYPE_BF16, dt2.ptr, dx.ptr, y.ptr, p3.ptr, ptr[0],
+                                         ptr[1], t1.ptr, p1.ptr, ptr[2], ptr[3], rows, Cm, C, N1),
+            "rn_conv_chain_forward_dt", ctx.handle)
+    ctx.sync()
+    yh = from_bf16_bits(_down_raw(y, np.uint16, rows * C)).reshape(B, H, W, C).transpose(0, 3, 1, 2).copy()
+    th = from_bf16_bits(_down_raw(t1, np.uint16, rows * N1)).reshape(B, H, W, N1).transpose(0, 3, 1, 2).copy()
+    return yh, th
+
+
 def conv2d_nhwc_pair(x, w, x2, w2, stride=1, pad=0, stride2=1, scale=None, scale2=None, shift=None,
                      residual=None, relu_: bool = False, bf16: bool = False) -> np.ndarray:
     """epilogue(conv(x, w * scale) + conv1x1(x2, w2 * scale2)) as ONE contraction:

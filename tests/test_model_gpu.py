@@ -357,6 +357,34 @@ def test_fused_stem_pool_changes_launches_not_results(state50, finch, golden_dir
         m.close()
 
 
+def test_chained_conv3_conv1_changes_launches_not_results(state50, finch):
+    """bf16 fused mode: conv3 of the 64-channel blocks and conv1 of the block after them as one launch
+    (rn_conv_chain_forward_dt, default on) against the separate launches: three ops fewer in
+    ResNet-50 (layer1.1 -> 1.2, layer1.2 -> layer2.0 ... and none out of the fused conv3 + downsample
+    pair), the same logits bit for bit, also with two streams and in sub-batches."""
+    m = R.NativeModel("resnet50", state=state50, dtype="bf16")
+    try:
+        x = np.concatenate([finch, R.weights.generate_input(130, seed=61)])
+        m.set_streams(1)
+        m.set_profiling(True)
+        chained = m.forward(x, fused=True)
+        ops_chained = [(r["op"], r["layer"]) for r in m.profile()]
+        m.set_chain(False)
+        plain = m.forward(x, fused=True)
+        ops_plain = [(r["op"], r["layer"]) for r in m.profile()]
+        m.set_profiling(False)
+        assert np.array_equal(chained, plain)
+        fused_ops = [l for o, l in ops_chained if o == "conv2d+epilogue+conv2d"]
+        assert fused_ops == ["layer1.1.conv3+next.conv1", "layer1.2.conv3+next.conv1"]
+        assert len(ops_plain) == len(ops_chained) + 2
+        m.set_chain(True)
+        m.set_streams(2)
+        assert np.array_equal(m.forward(x, fused=True), plain)
+        assert np.array_equal(m.forward(x[:3], fused=True), plain[:3])
+    finally:
+        m.close()
+
+
 def test_two_stream_forward_under_capture_pipeline_and_shards(state50, finch):
     """bf16 models run a batch of >= 128 images as two halves on two streams (fork / join events).
     The same forward captured as a hipGraph (a cross-stream capture), fed through the host
