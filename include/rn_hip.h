@@ -342,6 +342,15 @@ RN_API int rn_conv_chain_forward_dt(rn_ctx *ctx, int dtype, const void *t2, cons
                                     const float *shift3, void *t1, const void *packed_w1,
                                     const float *scale1, const float *shift1, uint64_t rows,
                                     uint64_t mid_channels, uint64_t channels, uint64_t next_mid);
+/* The same chain out of the fused conv3 + downsample pair of a stage's first block
+ * (rn_conv2d_nhwc_pair_forward_dt: panel from rn_conv2d_pack_weight_pair_dt with the scales folded
+ * in, K = mid + in2 channels, no residual): y = relu(t2 . w3s + x2 . wds + shift), then conv1.
+ * in2_channels 64. */
+RN_API int rn_conv_chain_pair_forward_dt(rn_ctx *ctx, int dtype, const void *t2, const void *x2,
+                                         void *y, const void *packed_pair, const float *shift,
+                                         void *t1, const void *packed_w1, const float *scale1,
+                                         const float *shift1, uint64_t rows, uint64_t mid_channels,
+                                         uint64_t in2_channels, uint64_t channels, uint64_t next_mid);
 /* Fused bf16 mode: conv3 of a 64-channel block and conv1 of the block after it as one launch
  * (rn_conv_chain_forward_dt; default on).  The same bits either way. */
 RN_API int rn_model_set_chain(rn_model *m, int on);

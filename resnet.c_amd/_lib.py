@@ -105,6 +105,7 @@ SIGNATURES = {
     "rn_stem_pool_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr, fptr, fptr, fptr, c_int, u64, u64, u64]),
     "rn_stem_pool_nchw_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr, fptr, fptr, fptr, c_int, u64, u64, u64, u64]),
     "rn_conv_chain_forward_dt": (c_int, [c_void_p, c_int] + [fptr] * 10 + [u64] * 4),
+    "rn_conv_chain_pair_forward_dt": (c_int, [c_void_p, c_int] + [fptr] * 9 + [u64] * 5),
     "rn_model_set_chain": (c_int, [c_void_p, c_int]),
     "rn_model_set_stem_pool_fusion": (c_int, [c_void_p, c_int]),
     "rn_model_set_streams": (c_int, [c_void_p, c_int]),

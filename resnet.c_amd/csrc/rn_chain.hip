@@ -34,7 +34,7 @@ namespace {
 
 struct ChainParams {
     const void *t2;  // [M][64]   conv3 input
-    const void *x;   // [M][256]  residual
+    const void *x;   // [M][256]  residual; DUAL: [M][64] the second contraction input (the block's input)
     void *y;         // [M][256]  conv3 output (the block's output)
     const void *w3;  // [256][64] packed K-major
     const float *sc3, *sh3;
@@ -42,7 +42,7 @@ struct ChainParams {
     const void *w1;  // [N1][256]
     const float *sc1, *sh1;
     int M, nsteps;
-    int t2_bytes, x_bytes, t1_bytes;
+    int t2_bytes, x_bytes, y_bytes, t1_bytes;
 };
 
 constexpr int kRows = 64;                          // rows of a step
@@ -64,8 +64,10 @@ __device__ __forceinline__ void pack4(const float (&v)[4], unsigned (&d)[2])
     d[1] = __builtin_bit_cast(unsigned, b);
 }
 
-// N1F: 32-channel fragments of conv1's output (2: 64 channels, 4: 128)
-template <int N1F>
+// N1F: 32-channel fragments of conv1's output (2: 64 channels, 4: 128).  DUAL: the first product is
+// the fused conv3 + downsample pair of a stage's first block -- K = 64 + 64 from two tensors,
+// batch-norm scales folded into the weight panel, no residual (rn_conv2d_nhwc_pair_forward_dt).
+template <int N1F, bool DUAL>
 __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
 {
     __shared__ __attribute__((aligned(16))) char lds[kLds];
@@ -88,11 +90,12 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
     // 32(w&1) .. +31 of the step and channel fragment w>>1 (waves past 2*N1F have none)
     const int pf2 = wave & 1, cf2 = wave >> 1;
     const bool has2 = cf2 < N1F;  // wave-uniform
-    i32x4 w3r[4], w1r[16];
+    constexpr int K3S = DUAL ? 8 : 4;  // k-steps of the first product
+    i32x4 w3r[K3S], w1r[16];
     {
-        const char *r3 = static_cast<const char *>(p.w3) + (size_t)(32 * wave + li) * 128 + lh * 16;
+        const char *r3 = static_cast<const char *>(p.w3) + (size_t)(32 * wave + li) * (K3S * 32) + lh * 16;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) w3r[ks] = *reinterpret_cast<const i32x4 *>(r3 + ks * 32);
+        for (int ks = 0; ks < K3S; ++ks) w3r[ks] = *reinterpret_cast<const i32x4 *>(r3 + ks * 32);
         const char *r1 = static_cast<const char *>(p.w1) + (size_t)(32 * (has2 ? cf2 : 0) + li) * 512 + lh * 16;
 #pragma unroll
         for (int s = 0; s < 16; ++s) w1r[s] = *reinterpret_cast<const i32x4 *>(r1 + s * 32);
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
 
     const i32x4 srd_t2 = make_srd(p.t2, p.t2_bytes);
     const i32x4 srd_x = make_srd(p.x, p.x_bytes);
-    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_t1 = __builtin_amdgcn_make_buffer_rsrc(p.t1, 0, p.t1_bytes, 0x00020000);
     const unsigned lds_base = (unsigned)(uintptr_t)((lds_void *)lds);
 
@@ -122,13 +125,19 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
             dma16((live && m < p.M) ? m * 128 + ((pc ^ ((r >> 1) & 7)) << 4) : kOob, srd_t2, 0,
                   lds_base + (unsigned)(kT2 + buf * kT2Bytes + wave * 1024));
         }
+        if constexpr (DUAL) {  // the second input's rows, in the same operand image as t2
+            const int r = 8 * wave + (lane >> 3), pc = lane & 7, m = m0 + r;
+            dma16((live && m < p.M) ? m * 128 + ((pc ^ ((r >> 1) & 7)) << 4) : kOob, srd_x, 0,
+                  lds_base + (unsigned)(kX + buf * kXBytes + wave * 1024));
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = 8 * j + wave;
-            const int r = 2 * q + (lane >> 5), sl = lane & 31, m = m0 + r;
-            const int c = (sl & ~15) | ((sl & 15) ^ (r & 15));  // global chunk held by LDS slot sl
-            dma16((live && m < p.M) ? m * 512 + (c << 4) : kOob, srd_x, 0,
-                  lds_base + (unsigned)(kX + buf * kXBytes + q * 1024));
+            for (int j = 0; j < 4; ++j) {
+                const int q = 8 * j + wave;
+                const int r = 2 * q + (lane >> 5), sl = lane & 31, m = m0 + r;
+                const int c = (sl & ~15) | ((sl & 15) ^ (r & 15));  // global chunk held by LDS slot sl
+                dma16((live && m < p.M) ? m * 512 + (c << 4) : kOob, srd_x, 0,
+                      lds_base + (unsigned)(kX + buf * kXBytes + q * 1024));
+            }
         }
     };
 
@@ -148,12 +157,13 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[pf][e] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < K3S; ++ks) {
 #pragma unroll
             for (int pf = 0; pf < 2; ++pf) {
                 const int r = 32 * pf + li;
+                const char *src = ks < 4 ? lds + kT2 + buf * kT2Bytes : lds + kX + buf * kXBytes;
                 const i32x4 px = *reinterpret_cast<const i32x4 *>(
-                    lds + kT2 + buf * kT2Bytes + r * 128 + (((2 * ks + lh) ^ ((r >> 1) & 7)) << 4));
+                    src + r * 128 + (((2 * (ks & 3) + lh) ^ ((r >> 1) & 7)) << 4));
                 acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w3r[ks]),
                                                                   __builtin_bit_cast(bf16x8, px), acc[pf], 0, 0, 0);
             }
@@ -170,13 +180,15 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
                 const int c4 = 32 * wave + 8 * j + 4 * lh;
                 const float4 sc = *reinterpret_cast<const float4 *>(ssl + c4);
                 const float4 sh = *reinterpret_cast<const float4 *>(ssl + 256 + c4);
-                const int chunk = 4 * wave + j;  // 16-byte chunk of the residual row
-                const bf16x4 rv = *reinterpret_cast<const bf16x4 *>(
-                    lds + kX + buf * kXBytes + r * 512 + (((chunk & ~15) | ((chunk & 15) ^ (r & 15))) << 4) + 8 * lh);
-                float v[4] = {fmaf(acc[pf][4 * j], sc.x, sh.x) + (float)rv[0],
-                              fmaf(acc[pf][4 * j + 1], sc.y, sh.y) + (float)rv[1],
-                              fmaf(acc[pf][4 * j + 2], sc.z, sh.z) + (float)rv[2],
-                              fmaf(acc[pf][4 * j + 3], sc.w, sh.w) + (float)rv[3]};
+                float v[4] = {fmaf(acc[pf][4 * j], sc.x, sh.x), fmaf(acc[pf][4 * j + 1], sc.y, sh.y),
+                              fmaf(acc[pf][4 * j + 2], sc.z, sh.z), fmaf(acc[pf][4 * j + 3], sc.w, sh.w)};
+                if constexpr (!DUAL) {
+                    const int chunk = 4 * wave + j;  // 16-byte chunk of the residual row
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4 *>(
+                        lds + kX + buf * kXBytes + r * 512 + (((chunk & ~15) | ((chunk & 15) ^ (r & 15))) << 4) + 8 * lh);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = v[k] + (float)rv[k];
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
                 pack4(v, d[j]);
@@ -240,6 +252,39 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
     }
 }
 
+int chain_launch(rn_ctx *ctx, const char *what, int dtype, const void *t2, const void *x, bool dual, void *y,
+                 const void *w3, const float *scale3, const float *shift3, void *t1, const void *w1,
+                 const float *scale1, const float *shift1, uint64_t rows, uint64_t mid_channels,
+                 uint64_t channels, uint64_t next_mid)
+{
+    if (rows == 0) return RN_OK;
+    RN_REQUIRE(ctx, dtype == RN_DTYPE_BF16, "bf16 storage only");
+    RN_REQUIRE(ctx, t2 && x && y && w3 && t1 && w1, "null tensor");
+    RN_REQUIRE(ctx, mid_channels == 64 && channels == 256 && (next_mid == 64 || next_mid == 128),
+               "shapes: 64 -> 256 -> 64 | 128 channels");
+    RN_REQUIRE(ctx, rows * 512 < (1ull << 31), "tensor too large");
+    ChainParams p;
+    p.t2 = t2, p.x = x, p.y = y, p.w3 = w3, p.sc3 = scale3, p.sh3 = shift3;
+    p.t1 = t1, p.w1 = w1, p.sc1 = scale1, p.sh1 = shift1;
+    p.M = (int)rows;
+    p.nsteps = (int)((rows + kRows - 1) / kRows);
+    p.t2_bytes = (int)(rows * 128), p.x_bytes = (int)(rows * (dual ? 128 : 512));
+    p.y_bytes = (int)(rows * 512), p.t1_bytes = (int)(rows * next_mid * 2);
+    const dim3 grid(p.nsteps < 256 ? p.nsteps : 256), block(512);  // one block per CU
+    if (dual) {
+        if (next_mid == 64)
+            chain_kernel<2, true><<<grid, block, 0, ctx->stream>>>(p);
+        else
+            chain_kernel<4, true><<<grid, block, 0, ctx->stream>>>(p);
+    } else {
+        if (next_mid == 64)
+            chain_kernel<2, false><<<grid, block, 0, ctx->stream>>>(p);
+        else
+            chain_kernel<4, false><<<grid, block, 0, ctx->stream>>>(p);
+    }
+    return rn_after_launch(ctx, what);
+}
+
 }  // namespace
 
 extern "C" {
@@ -252,25 +297,22 @@ int rn_conv_chain_forward_dt(rn_ctx *ctx, int dtype, const void *t2, const void 
                              uint64_t rows, uint64_t mid_channels, uint64_t channels, uint64_t next_mid)
 {
     RN_ENTER(ctx);
-    const char *what = "rn_conv_chain_forward_dt";
-    if (rows == 0) return RN_OK;
-    RN_REQUIRE(ctx, dtype == RN_DTYPE_BF16, "bf16 storage only");
-    RN_REQUIRE(ctx, t2 && residual && y && packed_w3 && t1 && packed_w1, "null tensor");
-    RN_REQUIRE(ctx, mid_channels == 64 && channels == 256 && (next_mid == 64 || next_mid == 128),
-               "shapes: 64 -> 256 -> 64 | 128 channels");
-    RN_REQUIRE(ctx, rows * 512 < (1ull << 31), "tensor too large");
-    ChainParams p;
-    p.t2 = t2, p.x = residual, p.y = y, p.w3 = packed_w3, p.sc3 = scale3, p.sh3 = shift3;
-    p.t1 = t1, p.w1 = packed_w1, p.sc1 = scale1, p.sh1 = shift1;
-    p.M = (int)rows;
-    p.nsteps = (int)((rows + kRows - 1) / kRows);
-    p.t2_bytes = (int)(rows * 128), p.x_bytes = (int)(rows * 512), p.t1_bytes = (int)(rows * next_mid * 2);
-    const int blocks = p.nsteps < 256 ? p.nsteps : 256;  // one block per CU
-    if (next_mid == 64)
-        chain_kernel<2><<<dim3(blocks), dim3(512), 0, ctx->stream>>>(p);
-    else
-        chain_kernel<4><<<dim3(blocks), dim3(512), 0, ctx->stream>>>(p);
-    return rn_after_launch(ctx, what);
+    return chain_launch(ctx, "rn_conv_chain_forward_dt", dtype, t2, residual, false, y, packed_w3, scale3, shift3,
+                        t1, packed_w1, scale1, shift1, rows, mid_channels, channels, next_mid);
+}
+
+// the same with the fused conv3 + downsample pair (rn_conv2d_pack_weight_pair_dt panel: scales
+// folded, K = mid + in2 channels) as the first product: y = relu(t2 . w3s + x2 . wds + shift)
+int rn_conv_chain_pair_forward_dt(rn_ctx *ctx, int dtype, const void *t2, const void *x2, void *y,
+                                  const void *packed_pair, const float *shift, void *t1,
+                                  const void *packed_w1, const float *scale1, const float *shift1,
+                                  uint64_t rows, uint64_t mid_channels, uint64_t in2_channels,
+                                  uint64_t channels, uint64_t next_mid)
+{
+    RN_ENTER(ctx);
+    RN_REQUIRE(ctx, in2_channels == 64, "second input: 64 channels");
+    return chain_launch(ctx, "rn_conv_chain_pair_forward_dt", dtype, t2, x2, true, y, packed_pair, nullptr, shift,
+                        t1, packed_w1, scale1, shift1, rows, mid_channels, channels, next_mid);
 }
 
 }  // extern "C"

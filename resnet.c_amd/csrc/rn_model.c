@@ -751,7 +751,10 @@ static int chain_applies(const rn_model *m, const rn_block *b, int mode)
     const int bi = (int)(b - m->blocks);
     const rn_conv *c3 = &m->convs[b->conv3], *n1;
     if (!m->chain || mode != RN_FWD_FUSED || m->dtype != RN_DTYPE_BF16 || m->recording) return 0;
-    if (b->ds >= 0 && m->pair_fusion) return 0; /* the pair has no residual operand: its own launch */
+    if (b->ds >= 0) { /* first block of a stage: only as the fused pair at equal resolution (stage 1) */
+        const rn_conv *cd = &m->convs[b->ds];
+        if (!m->pair_fusion || cd->stride != 1 || cd->cin != 64) return 0;
+    }
     if (bi + 1 >= m->n_blocks) return 0;
     if (m->front_parts > 1 && bi + 1 == m->depths[0]) return 0; /* the next block runs in another slice */
     n1 = &m->convs[m->blocks[bi + 1].conv1];
@@ -766,14 +769,24 @@ static int op_chain(rn_model *m, const rn_block *b, const void *t2, const void *
     const rn_conv *n1 = &m->convs[m->blocks[(b - m->blocks) + 1].conv1];
     const double M = (double)(B * H * W), es = (double)elem_size(m);
     char name[RN_MAX_KEY];
-    snprintf(name, sizeof(name), "%.*s+next.conv1", (int)(RN_MAX_KEY - 12), c3->name);
-    TRY(prof_begin(m, "conv2d+epilogue+conv2d", name,
-                   2.0 * M * ((double)c3->cout * (double)c3->cin + (double)n1->cout * (double)n1->cin),
-                   es * (M * (double)(c3->cin + 2 * c3->cout + n1->cout) +
-                         (double)(c3->cout * c3->cin + n1->cout * n1->cin))));
-    TRY(rn_conv_chain_forward_dt(m->run, m->dtype, t2, shortcut, y, c3->packed, c3->scale, c3->shift,
-                                 m->v.t1, n1->packed, n1->scale, n1->shift, B * H * W, c3->cin,
-                                 c3->cout, n1->cout));
+    snprintf(name, sizeof(name), "%.*s%s+next.conv1", (int)(RN_MAX_KEY - 24), c3->name, b->ds >= 0 ? "+downsample" : "");
+    {
+        const double k1 = (double)c3->cin + (b->ds >= 0 ? (double)m->convs[b->ds].cin : 0.0);
+        /* second operand of the first product: the residual (c3->cout channels) or the block input */
+        const double op2 = b->ds >= 0 ? (double)m->convs[b->ds].cin : (double)c3->cout;
+        TRY(prof_begin(m, "conv2d+epilogue+conv2d", name,
+                       2.0 * M * ((double)c3->cout * k1 + (double)n1->cout * (double)n1->cin),
+                       es * (M * ((double)c3->cin + op2 + (double)c3->cout + (double)n1->cout) +
+                             (double)c3->cout * k1 + (double)(n1->cout * n1->cin))));
+    }
+    if (b->ds >= 0) /* shortcut = the block's input: the downsample branch rides in the first product */
+        TRY(rn_conv_chain_pair_forward_dt(m->run, m->dtype, t2, shortcut, y, b->pair_packed, b->pair_shift,
+                                          m->v.t1, n1->packed, n1->scale, n1->shift, B * H * W, c3->cin,
+                                          m->convs[b->ds].cin, c3->cout, n1->cout));
+    else
+        TRY(rn_conv_chain_forward_dt(m->run, m->dtype, t2, shortcut, y, c3->packed, c3->scale, c3->shift,
+                                     m->v.t1, n1->packed, n1->scale, n1->shift, B * H * W, c3->cin,
+                                     c3->cout, n1->cout));
     m->t1_ready = 1;
     return prof_end(m);
 }
@@ -850,11 +863,11 @@ static int block_forward(rn_model *m, rn_block *b, const float *x, float *y, uin
             TRY(op_conv(m, c1, x, m->v.t1, B, h, w, &ep, -1));
         ep.scale = c2->scale; ep.shift = c2->shift;
         TRY(op_conv(m, c2, m->v.t1, m->v.t2, B, h, w, &ep, -1));
-        if (pair) {
+        if (chain_applies(m, b, mode)) {
+            TRY(op_chain(m, b, m->v.t2, pair ? x : shortcut, y, B, ho, wo));
+        } else if (pair) {
             /* the downsample tensor is never materialised: its K rows ride in conv3's loop */
             TRY(op_pair(m, b, m->v.t2, x, y, B, ho, wo, h, w));
-        } else if (chain_applies(m, b, mode)) {
-            TRY(op_chain(m, b, m->v.t2, shortcut, y, B, ho, wo));
         } else {
             ep.scale = c3->scale; ep.shift = c3->shift; ep.residual = shortcut;
             TRY(op_conv(m, c3, m->v.t2, y, B, ho, wo, &ep, -1));

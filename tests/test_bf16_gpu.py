@@ -250,6 +250,27 @@ def test_conv_chain_is_the_two_separate_launches_bit_for_bit(case):
         assert np.abs(got_y - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-5
 
 
+@pytest.mark.parametrize("case", [(3, 20, 20, 64), (2, 56, 56, 64), (1, 9, 7, 128)])
+def test_conv_chain_out_of_the_fused_pair_bit_for_bit(case):
+    """rn_conv_chain_pair_forward_dt: the fused conv3 + downsample pair (K = 64 + 64 from two
+    tensors, scales folded into the panel, no residual) as the chain's first product, against
+    rn_conv2d_nhwc_pair_forward_dt followed by the next block's conv1."""
+    B, H, W, N1 = case
+    seed = 760 + sum(case)
+    t2, x2 = rnd((B, 64, H, W), seed), rnd((B, 64, H, W), seed + 1)
+    w3, wd = rnd((256, 64, 1, 1), seed + 2) / 8.0, rnd((256, 64, 1, 1), seed + 3) / 8.0
+    w1 = rnd((N1, 256, 1, 1), seed + 4) / 16.0
+    g = np.random.default_rng(seed + 5)
+    sc3, scd = g.random(256, dtype=np.float32) + 0.5, g.random(256, dtype=np.float32) + 0.5
+    shift = g.standard_normal(256, dtype=np.float32)
+    sc1, sh1 = g.random(N1, dtype=np.float32) + 0.5, g.standard_normal(N1, dtype=np.float32)
+    want_y = ops.conv2d_nhwc_pair(t2, w3, x2, wd, 1, 0, 1, sc3, scd, shift, None, True, bf16=True)
+    want_t1 = ops.conv2d_nhwc_bf16(want_y, w1, 1, 0, sc1, sh1, None, True)
+    got_y, got_t1 = ops.conv_chain_pair_bf16(t2, x2, w3, sc3, wd, scd, shift, w1, sc1, sh1)
+    assert np.array_equal(got_y, want_y)
+    assert np.array_equal(got_t1, want_t1)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_wide_kernel_random_shapes_against_the_4_wave_kernel(seed):
     """Random geometry (image size, stride, padding, channel counts that leave ragged M and N
