@@ -37,8 +37,12 @@ if [ $what = pmc ] || [ $what = all ]; then
       rocprofv3 --pmc $c --output-format csv -d $o/pmc_${dt}_$c -- python3 bench.py --dtype $dt --streams 1 --steps 2 --warmup 1 --profile-forwards 1 --no-cpu-baseline --no-pipeline > /dev/null 2> $o/pmc_${dt}_$c.err
     done
   done
-  python tools/pmc_traffic.py $o/pmc_f32_FETCH_SIZE $o/pmc_f32_WRITE_SIZE $o/hbm_traffic_pmc_f32.json 72 24.97e9 "ResNet-50 fp32 B=256 fused; separate --pmc passes; FETCH_SIZE x2" > /dev/null
-  python tools/pmc_traffic.py $o/pmc_bf16_FETCH_SIZE $o/pmc_bf16_WRITE_SIZE $o/hbm_traffic_pmc_bf16.json 50 12.5e9 "ResNet-50 bf16 B=256 fused; separate --pmc passes; FETCH_SIZE x2" > /dev/null
+  # launches per forward and algorithmic bytes of the contraction family: what a bench line of this build says
+  for dt in f32 bf16; do
+    python3 bench.py --dtype $dt --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > $o/pmc_ref_$dt.json 2> /dev/null
+    read n bytes <<< $(python3 -c "import json;r=json.loads(open('$o/pmc_ref_$dt.json').read().strip().splitlines()[-1])['roofline'];print(r['launches_per_forward'], r['bytes_per_forward'])")
+    python tools/pmc_traffic.py $o/pmc_${dt}_FETCH_SIZE $o/pmc_${dt}_WRITE_SIZE $o/hbm_traffic_pmc_$dt.json $n $bytes "ResNet-50 $dt B=256 fused; separate --pmc passes; FETCH_SIZE x2" > /dev/null
+  done
   find $o -name '*counter_collection.csv' -size +8M -delete
 fi
 ls -la $o | head -60

@@ -20,6 +20,8 @@ def family(name):
         return "stem_pool_kernel"
     if "conv_strip_kernel" in name:
         return "conv_strip_kernel"
+    if "chain_kernel" in name:
+        return "chain_kernel"
     if "maxpool3_nhwc_kernel" in name:
         return "maxpool3_nhwc_kernel"
     n = name.replace("void ", "").replace("(anonymous namespace)::", "")
@@ -46,7 +48,7 @@ def main():
     # the contraction family as bench.py's `roofline` counts it: the implicit-GEMM launches plus
     # the launches that add the K-chunk pieces of cut tail tiles
     con = [v for k, v in fam.items()
-           if k in ("conv_gemm_kernel", "conv_wide_kernel", "conv_strip_kernel", "splitk_finish_kernel", "stem_pool_kernel")]
+           if k in ("conv_gemm_kernel", "conv_wide_kernel", "conv_strip_kernel", "chain_kernel", "splitk_finish_kernel", "stem_pool_kernel")]
     if con:
         n, ns = sum(v[0] for v in con), sum(v[1] for v in con)
         out["contraction_family"] = {"launches_per_forward": n / F, "avg_us": ns / n / 1e3,

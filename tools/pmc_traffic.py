@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic of the contraction kernels from two rocprofv3 --pmc passes (FETCH_SIZE and
 WRITE_SIZE cannot share a pass on gfx950: TCC slot limit).  Uses the contraction dispatches
-(conv_gemm_kernel, conv_wide_kernel, splitk_finish_kernel, stem_pool_kernel) of the LAST forward of each run;
+(conv_gemm_kernel, conv_wide_kernel, conv_strip_kernel, chain_kernel, splitk_finish_kernel, stem_pool_kernel) of the LAST forward of each run;
 FETCH_SIZE is doubled (gfx950 reports half the bytes of a wide coalesced read stream,
 MI355X_MICROARCH.md section HBM); both counters are in KiB.
 
@@ -14,7 +14,8 @@ import os
 import sys
 
 
-FAMILY = ("conv_gemm_kernel", "conv_wide_kernel", "splitk_finish_kernel", "stem_pool_kernel")
+FAMILY = ("conv_gemm_kernel", "conv_wide_kernel", "conv_strip_kernel", "chain_kernel", "splitk_finish_kernel",
+          "stem_pool_kernel")
 
 
 def last_forward(d, counter, n):
