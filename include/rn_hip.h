@@ -335,8 +335,8 @@ RN_API int rn_stem_pool_nchw_forward_dt(rn_ctx *ctx, int dtype, const float *inp
  * (layerForward, main.cu:131-164, end of one pass and start of the next) as ONE launch on bf16
  * NHWC tensors: t2 [rows][mid] -> y [rows][channels] (written: the next block's residual) ->
  * t1 [rows][next_mid]; y reaches conv1 through LDS instead of HBM.  The same bits as the two
- * separate rn_conv2d_nhwc_forward_dt calls.  mid 64, channels 256, next_mid 64 or 128; packed
- * weights from rn_conv2d_pack_weight_dt; scale/shift may be NULL. */
+ * separate rn_conv2d_nhwc_forward_dt calls.  (mid, channels, next_mid) = (64, 256, 64 | 128) or
+ * (128, 512, 128); packed weights from rn_conv2d_pack_weight_dt; scale/shift may be NULL. */
 RN_API int rn_conv_chain_forward_dt(rn_ctx *ctx, int dtype, const void *t2, const void *residual,
                                     void *y, const void *packed_w3, const float *scale3,
                                     const float *shift3, void *t1, const void *packed_w1,

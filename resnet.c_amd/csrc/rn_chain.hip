@@ -45,13 +45,6 @@ struct ChainParams {
     int t2_bytes, x_bytes, y_bytes, t1_bytes;
 };
 
-constexpr int kRows = 64;                          // rows of a step
-constexpr int kT2 = 0, kT2Bytes = kRows * 128;     // two t2 buffers
-constexpr int kX = 2 * kT2Bytes, kXBytes = kRows * 512;  // two residual buffers
-constexpr int kY = kX + 2 * kXBytes;               // y tile: 4 K tiles of [64][128 B]
-constexpr int kS = kY + kRows * 512;               // scale3[256] shift3[256] scale1[128] shift1[128]
-constexpr int kLds = kS + (512 + 256) * 4;
-
 typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
 typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -64,18 +57,42 @@ __device__ __forceinline__ void pack4(const float (&v)[4], unsigned (&d)[2])
     d[1] = __builtin_bit_cast(unsigned, b);
 }
 
-// N1F: 32-channel fragments of conv1's output (2: 64 channels, 4: 128).  DUAL: the first product is
-// the fused conv3 + downsample pair of a stage's first block -- K = 64 + 64 from two tensors,
-// batch-norm scales folded into the weight panel, no residual (rn_conv2d_nhwc_pair_forward_dt).
-template <int N1F, bool DUAL>
-__global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
+// Geometry per mid-channel count MID (block channels C = 4 MID):
+//   MID  64: 8 waves, 64 rows per step; a wave owns 32 of the 256 channels of the first product
+//   MID 128: 4 waves, 32 rows per step; a wave owns 128 of the 512 channels -- one wave per SIMD,
+//            so that its 128 + 128 weight registers and 80 accumulator registers fit the SIMD's
+//            512, and a residual double buffer of 2 x 32 KB instead of 2 x 64 fits LDS
+template <int MID>
+struct Geo {
+    static constexpr int C = 4 * MID;
+    static constexpr int WAVES = MID == 64 ? 8 : 4;
+    static constexpr int ROWS = MID == 64 ? 64 : 32;
+    static constexpr int PF = ROWS / 32;             // 32-row fragments of a step
+    static constexpr int CF1 = C / (32 * WAVES);     // channel fragments of the first product per wave
+    static constexpr int KT2 = MID / 64;             // 128-byte K tiles of a t2 row
+    static constexpr int T2B = ROWS * MID * 2;       // bytes of a t2 buffer
+    static constexpr int XB = ROWS * C * 2;          // bytes of a residual buffer (= of the y tile)
+    static constexpr int oT2 = 0, oX = 2 * T2B, oY = oX + 2 * XB, oS = oY + XB;
+    static constexpr int LDS = oS + (2 * C + 512) * 4;  // + scale/shift of both products
+};
+
+// N1: channels of the second product (conv1 of the next block).  DUAL (MID 64 only): the first
+// product is the fused conv3 + downsample pair of a stage's first block -- K = 64 + 64 from two
+// tensors, batch-norm scales folded into the weight panel, no residual
+// (rn_conv2d_nhwc_pair_forward_dt).
+template <int MID, int N1, bool DUAL>
+__global__ __launch_bounds__(64 * Geo<MID>::WAVES) void chain_kernel(const ChainParams p)
 {
-    __shared__ __attribute__((aligned(16))) char lds[kLds];
-    float *const ssl = reinterpret_cast<float *>(lds + kS);
+    using G = Geo<MID>;
+    constexpr int C = G::C, ROWS = G::ROWS, PF = G::PF, CF1 = G::CF1, THREADS = 64 * G::WAVES;
+    constexpr int N1F = N1 / 32;
+    static_assert(!DUAL || MID == 64, "pair chain: 64 mid channels");
+    static_assert(PF * N1F <= G::WAVES, "one fragment of the second product per wave");
+    __shared__ __attribute__((aligned(16))) char lds[G::LDS];
+    float *const ssl = reinterpret_cast<float *>(lds + G::oS);  // sc3[C] sh3[C] sc1[256] sh1[256]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    constexpr int N1 = 32 * N1F;
 
     // this block's steps: a contiguous range, the remainder to the first blocks
     int nst, s0;
@@ -86,27 +103,31 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
         s0 = (int)(v * base + min(v, rem));
     }
 
-    // weights: conv3 -- wave w owns output channels 32w .. 32w+31; conv1 -- wave w owns rows
-    // 32(w&1) .. +31 of the step and channel fragment w>>1 (waves past 2*N1F have none)
-    const int pf2 = wave & 1, cf2 = wave >> 1;
+    // weights.  First product: wave w owns channel fragments CF1*w .. CF1*w + CF1-1.  Second: wave w
+    // owns rows 32(w % PF) .. +31 of the step and channel fragment w / PF (waves past PF*N1F: none)
+    const int pf2 = wave % PF, cf2 = wave / PF;
     const bool has2 = cf2 < N1F;  // wave-uniform
-    constexpr int K3S = DUAL ? 8 : 4;  // k-steps of the first product
-    i32x4 w3r[K3S], w1r[16];
+    constexpr int K3S = (DUAL ? 2 : 1) * MID / 16;  // k-steps of the first product
+    constexpr int K1S = C / 16;                     // ... of the second
+    i32x4 w3r[CF1][K3S], w1r[K1S];
+#pragma unroll
+    for (int f = 0; f < CF1; ++f) {
+        const char *r3 = static_cast<const char *>(p.w3) + (size_t)(32 * (CF1 * wave + f) + li) * (K3S * 32) + lh * 16;
+#pragma unroll
+        for (int ks = 0; ks < K3S; ++ks) w3r[f][ks] = *reinterpret_cast<const i32x4 *>(r3 + ks * 32);
+    }
     {
-        const char *r3 = static_cast<const char *>(p.w3) + (size_t)(32 * wave + li) * (K3S * 32) + lh * 16;
+        const char *r1 = static_cast<const char *>(p.w1) + (size_t)(32 * (has2 ? cf2 : 0) + li) * (K1S * 32) + lh * 16;
 #pragma unroll
-        for (int ks = 0; ks < K3S; ++ks) w3r[ks] = *reinterpret_cast<const i32x4 *>(r3 + ks * 32);
-        const char *r1 = static_cast<const char *>(p.w1) + (size_t)(32 * (has2 ? cf2 : 0) + li) * 512 + lh * 16;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) w1r[s] = *reinterpret_cast<const i32x4 *>(r1 + s * 32);
+        for (int s = 0; s < K1S; ++s) w1r[s] = *reinterpret_cast<const i32x4 *>(r1 + s * 32);
     }
-    for (int i = t; i < 256; i += 512) {
+    for (int i = t; i < C; i += THREADS) {
         ssl[i] = p.sc3 ? p.sc3[i] : 1.f;
-        ssl[256 + i] = p.sh3 ? p.sh3[i] : -0.f;  // -0.0 keeps a -0.0 sum
+        ssl[C + i] = p.sh3 ? p.sh3[i] : -0.f;  // -0.0 keeps a -0.0 sum
     }
-    for (int i = t; i < N1; i += 512) {
-        ssl[512 + i] = p.sc1 ? p.sc1[i] : 1.f;
-        ssl[640 + i] = p.sh1 ? p.sh1[i] : -0.f;
+    for (int i = t; i < N1; i += THREADS) {
+        ssl[2 * C + i] = p.sc1 ? p.sc1[i] : 1.f;
+        ssl[2 * C + 256 + i] = p.sh1 ? p.sh1[i] : -0.f;
     }
 
     const i32x4 srd_t2 = make_srd(p.t2, p.t2_bytes);
@@ -115,28 +136,36 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
     const __amdgpu_buffer_rsrc_t rsrc_t1 = __builtin_amdgcn_make_buffer_rsrc(p.t1, 0, p.t1_bytes, 0x00020000);
     const unsigned lds_base = (unsigned)(uintptr_t)((lds_void *)lds);
 
-    // the DMA pieces of step s into buffer `buf`: one of t2 (rows 8w .. 8w+7), four of the residual
-    // (piece q = 8j + w holds rows 2q, 2q+1)
+    // the DMA pieces (1 KiB each) of step s into buffer `buf`.  t2: K tile kt, rows 8i .. 8i+7 in
+    // the MFMA operand image; residual: consecutive 16-byte slots of the [ROWS][2C-byte] rows, slot
+    // sl of row r holding the row's chunk sl ^ (r & 15) (low four bits)
     auto fetch = [&](int s, int buf) {
-        const int m0 = (s0 + s) * kRows;
+        const int m0 = (s0 + s) * ROWS;
         const bool live = s < nst;
-        {
-            const int r = 8 * wave + (lane >> 3), pc = lane & 7, m = m0 + r;
-            dma16((live && m < p.M) ? m * 128 + ((pc ^ ((r >> 1) & 7)) << 4) : kOob, srd_t2, 0,
-                  lds_base + (unsigned)(kT2 + buf * kT2Bytes + wave * 1024));
+        constexpr int T2P = G::KT2 * ROWS / 8;  // pieces of a t2 buffer
+#pragma unroll
+        for (int j = 0; j < T2P / G::WAVES; ++j) {
+            const int q = G::WAVES * j + wave, kt = q / (ROWS / 8), r = 8 * (q % (ROWS / 8)) + (lane >> 3);
+            const int pc = lane & 7, m = m0 + r;
+            dma16((live && m < p.M) ? m * (MID * 2) + kt * 128 + ((pc ^ ((r >> 1) & 7)) << 4) : kOob, srd_t2, 0,
+                  lds_base + (unsigned)(G::oT2 + buf * G::T2B + q * 1024));
         }
         if constexpr (DUAL) {  // the second input's rows, in the same operand image as t2
-            const int r = 8 * wave + (lane >> 3), pc = lane & 7, m = m0 + r;
-            dma16((live && m < p.M) ? m * 128 + ((pc ^ ((r >> 1) & 7)) << 4) : kOob, srd_x, 0,
-                  lds_base + (unsigned)(kX + buf * kXBytes + wave * 1024));
-        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int q = 8 * j + wave;
-                const int r = 2 * q + (lane >> 5), sl = lane & 31, m = m0 + r;
-                const int c = (sl & ~15) | ((sl & 15) ^ (r & 15));  // global chunk held by LDS slot sl
-                dma16((live && m < p.M) ? m * 512 + (c << 4) : kOob, srd_x, 0,
-                      lds_base + (unsigned)(kX + buf * kXBytes + q * 1024));
+            for (int j = 0; j < T2P / G::WAVES; ++j) {
+                const int q = G::WAVES * j + wave, r = 8 * q + (lane >> 3), pc = lane & 7, m = m0 + r;
+                dma16((live && m < p.M) ? m * 128 + ((pc ^ ((r >> 1) & 7)) << 4) : kOob, srd_x, 0,
+                      lds_base + (unsigned)(G::oX + buf * G::XB + q * 1024));
+            }
+        } else {
+            constexpr int XP = G::XB / 1024, SPR = C / 8;  // pieces; 16-byte slots per row
+#pragma unroll
+            for (int j = 0; j < XP / G::WAVES; ++j) {
+                const int q = G::WAVES * j + wave, g = 64 * q + lane;
+                const int r = g / SPR, sl = g % SPR, m = m0 + r;
+                const int c = (sl & ~15) | ((sl & 15) ^ (r & 15));
+                dma16((live && m < p.M) ? m * (C * 2) + (c << 4) : kOob, srd_x, 0,
+                      lds_base + (unsigned)(G::oX + buf * G::XB + q * 1024));
             }
         }
     };
@@ -144,88 +173,97 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
     fetch(0, 0);
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
-        const int m0 = (s0 + s) * kRows;
+        const int m0 = (s0 + s) * ROWS;
         // this step's rows have landed (and the previous step's stores are out), all waves are past
         // the previous step: its buffers take the next step's rows
         wait_and_barrier<0>();
         fetch(s + 1, buf ^ 1);
 
-        // ---- conv3: y[64][256] = t2[64][64] . w3^T, wave w the channels 32w .. 32w+31 ----
-        f32x16 acc[2];
+        // ---- first product: y[ROWS][C] = t2[ROWS][MID] . w3^T (+ second input . wd^T) ----
+        f32x16 acc[PF][CF1];
 #pragma unroll
-        for (int pf = 0; pf < 2; ++pf)
+        for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[pf][e] = 0.f;
+            for (int f = 0; f < CF1; ++f)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[pf][f][e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < K3S; ++ks) {
 #pragma unroll
-            for (int pf = 0; pf < 2; ++pf) {
+            for (int pf = 0; pf < PF; ++pf) {
                 const int r = 32 * pf + li;
-                const char *src = ks < 4 ? lds + kT2 + buf * kT2Bytes : lds + kX + buf * kXBytes;
+                const bool second = DUAL && ks >= MID / 16;
+                const int kk = second ? ks - MID / 16 : ks;
+                const char *src = second ? lds + G::oX + buf * G::XB : lds + G::oT2 + buf * G::T2B;
                 const i32x4 px = *reinterpret_cast<const i32x4 *>(
-                    src + r * 128 + (((2 * (ks & 3) + lh) ^ ((r >> 1) & 7)) << 4));
-                acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w3r[ks]),
-                                                                  __builtin_bit_cast(bf16x8, px), acc[pf], 0, 0, 0);
+                    src + (kk >> 2) * (ROWS * 128) + r * 128 + (((2 * (kk & 3) + lh) ^ ((r >> 1) & 7)) << 4));
+#pragma unroll
+                for (int f = 0; f < CF1; ++f)
+                    acc[pf][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w3r[f][ks]),
+                                                                         __builtin_bit_cast(bf16x8, px), acc[pf][f], 0, 0, 0);
             }
         }
-        // lane (li, lh): channels 32w + 8j + 4lh + {0..3}, j = 0..3, of row 32pf + li.  Affine,
+        // lane (li, lh): channels 32cf + 8j + 4lh + {0..3}, j = 0..3, of row 32pf + li.  Affine,
         // residual (8 bytes from the swizzled LDS rows), ReLU, bf16; the half-waves trade groups so
         // that each lane owns 8 consecutive channels = one 16-byte chunk of the y tile.
 #pragma unroll
-        for (int pf = 0; pf < 2; ++pf) {
-            const int r = 32 * pf + li;
-            unsigned d[4][2];
+        for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c4 = 32 * wave + 8 * j + 4 * lh;
-                const float4 sc = *reinterpret_cast<const float4 *>(ssl + c4);
-                const float4 sh = *reinterpret_cast<const float4 *>(ssl + 256 + c4);
-                float v[4] = {fmaf(acc[pf][4 * j], sc.x, sh.x), fmaf(acc[pf][4 * j + 1], sc.y, sh.y),
-                              fmaf(acc[pf][4 * j + 2], sc.z, sh.z), fmaf(acc[pf][4 * j + 3], sc.w, sh.w)};
-                if constexpr (!DUAL) {
-                    const int chunk = 4 * wave + j;  // 16-byte chunk of the residual row
-                    const bf16x4 rv = *reinterpret_cast<const bf16x4 *>(
-                        lds + kX + buf * kXBytes + r * 512 + (((chunk & ~15) | ((chunk & 15) ^ (r & 15))) << 4) + 8 * lh);
+            for (int f = 0; f < CF1; ++f) {
+                const int r = 32 * pf + li, cf = CF1 * wave + f;
+                unsigned d[4][2];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = v[k] + (float)rv[k];
+                for (int j = 0; j < 4; ++j) {
+                    const int c4 = 32 * cf + 8 * j + 4 * lh;
+                    const float4 sc = *reinterpret_cast<const float4 *>(ssl + c4);
+                    const float4 sh = *reinterpret_cast<const float4 *>(ssl + C + c4);
+                    float v[4] = {fmaf(acc[pf][f][4 * j], sc.x, sh.x), fmaf(acc[pf][f][4 * j + 1], sc.y, sh.y),
+                                  fmaf(acc[pf][f][4 * j + 2], sc.z, sh.z), fmaf(acc[pf][f][4 * j + 3], sc.w, sh.w)};
+                    if constexpr (!DUAL) {
+                        const int chunk = 4 * cf + j;  // 16-byte chunk of the residual row
+                        const bf16x4 rv = *reinterpret_cast<const bf16x4 *>(
+                            lds + G::oX + buf * G::XB + r * (C * 2) +
+                            (((chunk & ~15) | ((chunk & 15) ^ (r & 15))) << 4) + 8 * lh);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = v[k] + (float)rv[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                    pack4(v, d[j]);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-                pack4(v, d[j]);
+                for (int h = 0; h < 2; ++h) {
+                    const auto x0 = __builtin_amdgcn_permlane32_swap(d[2 * h][0], d[2 * h + 1][0], false, false);
+                    const auto x1 = __builtin_amdgcn_permlane32_swap(d[2 * h][1], d[2 * h + 1][1], false, false);
+                    // channels 32cf + 16h + 8lh + {0..7}: chunk 4cf + 2h + lh of the C-channel row
+                    const int cy = 4 * cf + 2 * h + lh;
+                    *reinterpret_cast<i32x4 *>(lds + G::oY + (cy >> 3) * (ROWS * 128) + r * 128 +
+                                               (((cy & 7) ^ ((r >> 1) & 7)) << 4)) =
+                        i32x4{(int)x0[0], (int)x1[0], (int)x0[1], (int)x1[1]};
+                }
             }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const auto x0 = __builtin_amdgcn_permlane32_swap(d[2 * h][0], d[2 * h + 1][0], false, false);
-                const auto x1 = __builtin_amdgcn_permlane32_swap(d[2 * h][1], d[2 * h + 1][1], false, false);
-                // channels 32w + 16h + 8lh + {0..7}: chunk 4w + 2h + lh of the 256-channel row
-                const int cy = 4 * wave + 2 * h + lh;
-                *reinterpret_cast<i32x4 *>(lds + kY + (cy >> 3) * (kRows * 128) + r * 128 +
-                                           (((cy & 7) ^ ((r >> 1) & 7)) << 4)) =
-                    i32x4{(int)x0[0], (int)x1[0], (int)x0[1], (int)x1[1]};
-            }
-        }
         __syncthreads();
 
         // ---- y leaves as whole rows ----
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (t >> 5) + 16 * i, c = t & 31, m = m0 + r;
-            const i32x4 v = *reinterpret_cast<const i32x4 *>(lds + kY + (c >> 3) * (kRows * 128) + r * 128 +
+        for (int i = 0; i < ROWS * (C / 8) / THREADS; ++i) {
+            const int g = t + i * THREADS, r = g / (C / 8), c = g % (C / 8), m = m0 + r;
+            const i32x4 v = *reinterpret_cast<const i32x4 *>(lds + G::oY + (c >> 3) * (ROWS * 128) + r * 128 +
                                                              (((c & 7) ^ ((r >> 1) & 7)) << 4));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc_y,
-                                                   m < p.M ? m * 512 + (c << 4) : kOob, 0, 0);
+                                                   m < p.M ? m * (C * 2) + (c << 4) : kOob, 0, 0);
         }
 
-        // ---- conv1: t1[64][N1] = y[64][256] . w1^T ----
+        // ---- second product: t1[ROWS][N1] = y[ROWS][C] . w1^T ----
         if (has2) {
             const int r = 32 * pf2 + li;
             f32x16 a2;
 #pragma unroll
             for (int e = 0; e < 16; ++e) a2[e] = 0.f;
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) {
+            for (int s2 = 0; s2 < K1S; ++s2) {
                 const i32x4 px = *reinterpret_cast<const i32x4 *>(
-                    lds + kY + (s2 >> 2) * (kRows * 128) + r * 128 + (((2 * (s2 & 3) + lh) ^ ((r >> 1) & 7)) << 4));
+                    lds + G::oY + (s2 >> 2) * (ROWS * 128) + r * 128 + (((2 * (s2 & 3) + lh) ^ ((r >> 1) & 7)) << 4));
                 a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1r[s2]),
                                                              __builtin_bit_cast(bf16x8, px), a2, 0, 0, 0);
             }
@@ -233,8 +271,8 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c4 = 32 * cf2 + 8 * j + 4 * lh;
-                const float4 sc = *reinterpret_cast<const float4 *>(ssl + 512 + c4);
-                const float4 sh = *reinterpret_cast<const float4 *>(ssl + 640 + c4);
+                const float4 sc = *reinterpret_cast<const float4 *>(ssl + 2 * C + c4);
+                const float4 sh = *reinterpret_cast<const float4 *>(ssl + 2 * C + 256 + c4);
                 float v[4] = {fmaxf(fmaf(a2[4 * j], sc.x, sh.x), 0.f), fmaxf(fmaf(a2[4 * j + 1], sc.y, sh.y), 0.f),
                               fmaxf(fmaf(a2[4 * j + 2], sc.z, sh.z), 0.f), fmaxf(fmaf(a2[4 * j + 3], sc.w, sh.w), 0.f)};
                 pack4(v, d[j]);
@@ -252,6 +290,13 @@ __global__ __launch_bounds__(512, 2) void chain_kernel(const ChainParams p)
     }
 }
 
+template <int MID, int N1, bool DUAL>
+void chain_go(rn_ctx *ctx, const ChainParams &p)
+{
+    const int blocks = p.nsteps < 256 ? p.nsteps : 256;  // one block per CU
+    chain_kernel<MID, N1, DUAL><<<dim3(blocks), dim3(64 * Geo<MID>::WAVES), 0, ctx->stream>>>(p);
+}
+
 int chain_launch(rn_ctx *ctx, const char *what, int dtype, const void *t2, const void *x, bool dual, void *y,
                  const void *w3, const float *scale3, const float *shift3, void *t1, const void *w1,
                  const float *scale1, const float *shift1, uint64_t rows, uint64_t mid_channels,
@@ -260,28 +305,24 @@ int chain_launch(rn_ctx *ctx, const char *what, int dtype, const void *t2, const
     if (rows == 0) return RN_OK;
     RN_REQUIRE(ctx, dtype == RN_DTYPE_BF16, "bf16 storage only");
     RN_REQUIRE(ctx, t2 && x && y && w3 && t1 && w1, "null tensor");
-    RN_REQUIRE(ctx, mid_channels == 64 && channels == 256 && (next_mid == 64 || next_mid == 128),
-               "shapes: 64 -> 256 -> 64 | 128 channels");
-    RN_REQUIRE(ctx, rows * 512 < (1ull << 31), "tensor too large");
+    const bool s1 = mid_channels == 64 && channels == 256 && (next_mid == 64 || next_mid == 128);
+    const bool s2 = mid_channels == 128 && channels == 512 && next_mid == 128 && !dual;
+    RN_REQUIRE(ctx, s1 || s2, "shapes: 64 -> 256 -> 64 | 128 channels, or 128 -> 512 -> 128");
+    RN_REQUIRE(ctx, rows * channels * 2 < (1ull << 31), "tensor too large");
     ChainParams p;
     p.t2 = t2, p.x = x, p.y = y, p.w3 = w3, p.sc3 = scale3, p.sh3 = shift3;
     p.t1 = t1, p.w1 = w1, p.sc1 = scale1, p.sh1 = shift1;
     p.M = (int)rows;
-    p.nsteps = (int)((rows + kRows - 1) / kRows);
-    p.t2_bytes = (int)(rows * 128), p.x_bytes = (int)(rows * (dual ? 128 : 512));
-    p.y_bytes = (int)(rows * 512), p.t1_bytes = (int)(rows * next_mid * 2);
-    const dim3 grid(p.nsteps < 256 ? p.nsteps : 256), block(512);  // one block per CU
-    if (dual) {
-        if (next_mid == 64)
-            chain_kernel<2, true><<<grid, block, 0, ctx->stream>>>(p);
-        else
-            chain_kernel<4, true><<<grid, block, 0, ctx->stream>>>(p);
-    } else {
-        if (next_mid == 64)
-            chain_kernel<2, false><<<grid, block, 0, ctx->stream>>>(p);
-        else
-            chain_kernel<4, false><<<grid, block, 0, ctx->stream>>>(p);
-    }
+    const uint64_t step = s1 ? 64 : 32;
+    p.nsteps = (int)((rows + step - 1) / step);
+    p.t2_bytes = (int)(rows * mid_channels * 2), p.x_bytes = (int)(rows * (dual ? 128 : channels * 2));
+    p.y_bytes = (int)(rows * channels * 2), p.t1_bytes = (int)(rows * next_mid * 2);
+    if (s2)
+        chain_go<128, 128, false>(ctx, p);
+    else if (dual)
+        next_mid == 64 ? chain_go<64, 64, true>(ctx, p) : chain_go<64, 128, true>(ctx, p);
+    else
+        next_mid == 64 ? chain_go<64, 64, false>(ctx, p) : chain_go<64, 128, false>(ctx, p);
     return rn_after_launch(ctx, what);
 }
 

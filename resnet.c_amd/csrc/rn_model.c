@@ -96,7 +96,7 @@ struct rn_model {
     int pair_fusion;  /* fused mode: conv3 + downsample as one contraction (default on) */
     int stem_exact;   /* fp32: stem in the exact-K form, K = 160 instead of 224 (default on) */
     float *stem_packed_exact;
-    int chain;               /* fused bf16 mode: conv3 of a 64-channel block + conv1 of the next block as one launch (default on) */
+    int chain;               /* fused bf16 mode: conv3 of a 64- / 128-channel block + conv1 of the next block as one launch (default on) */
     int t1_ready;            /* the previous block's chained launch has produced this block's conv1 output */
     int stem_pool;           /* fused mode: stem + batch-norm + ReLU + max-pool as one launch (default on) */
     void *stem_pool_packed;  /* its weight panel, model dtype */
@@ -758,8 +758,9 @@ static int chain_applies(const rn_model *m, const rn_block *b, int mode)
     if (bi + 1 >= m->n_blocks) return 0;
     if (m->front_parts > 1 && bi + 1 == m->depths[0]) return 0; /* the next block runs in another slice */
     n1 = &m->convs[m->blocks[bi + 1].conv1];
-    return c3->k == 1 && c3->stride == 1 && c3->cin == 64 && c3->cout == 256 && n1->k == 1 &&
-           n1->stride == 1 && n1->cin == 256 && (n1->cout == 64 || n1->cout == 128);
+    if (c3->k != 1 || c3->stride != 1 || n1->k != 1 || n1->stride != 1 || n1->cin != c3->cout) return 0;
+    if (c3->cin == 64 && c3->cout == 256) return n1->cout == 64 || n1->cout == 128;
+    return c3->cin == 128 && c3->cout == 512 && n1->cout == 128 && b->ds < 0;
 }
 
 static int op_chain(rn_model *m, const rn_block *b, const void *t2, const void *shortcut, void *y,

@@ -225,19 +225,22 @@ def test_strip_kernel_full_size_under_load():
         lib.rn_ctx_set_conv_tile(ctx.handle, 0)
 
 
-@pytest.mark.parametrize("case", [(3, 20, 20, 64), (1, 8, 8, 64), (2, 56, 56, 128), (5, 13, 9, 128)])
+@pytest.mark.parametrize("case", [(3, 20, 20, 64, 64), (1, 8, 8, 64, 64), (2, 56, 56, 64, 128), (5, 13, 9, 64, 128),
+                                  (2, 28, 28, 128, 128), (3, 9, 7, 128, 128), (1, 4, 8, 128, 128)])
 def test_conv_chain_is_the_two_separate_launches_bit_for_bit(case):
     """rn_conv_chain_forward_dt (conv3 + bn3 + residual + ReLU of a block, conv1 + bn1 + ReLU of the
     next, y through LDS) against the two rn_conv2d_nhwc_forward_dt calls it replaces: y and t1 bit
     for bit -- same k order, same epilogue expression, y rounded to bf16 before conv1 multiplies
-    it -- and y against the oracle.  Ragged last step (1200 and 585 rows), one-step launch (64
-    rows), both widths of the next block's conv1."""
-    B, H, W, N1 = case
+    it -- and y against the oracle.  64 mid channels (8 waves, 64-row steps; both widths of the
+    next block's conv1) and 128 (4 waves with 448 registers each, 32-row steps); ragged last
+    steps (1200, 585 and 189 rows), one-step launches."""
+    B, H, W, MID, N1 = case
+    C = 4 * MID
     seed = 700 + sum(case)
-    t2, x = rnd((B, 64, H, W), seed), rnd((B, 256, H, W), seed + 1)
-    w3, w1 = rnd((256, 64, 1, 1), seed + 2) / 8.0, rnd((N1, 256, 1, 1), seed + 3) / 16.0
+    t2, x = rnd((B, MID, H, W), seed), rnd((B, C, H, W), seed + 1)
+    w3, w1 = rnd((C, MID, 1, 1), seed + 2) / np.sqrt(MID), rnd((N1, C, 1, 1), seed + 3) / np.sqrt(C)
     g = np.random.default_rng(seed + 4)
-    sc3, sh3 = g.random(256, dtype=np.float32) + 0.5, g.standard_normal(256, dtype=np.float32)
+    sc3, sh3 = g.random(C, dtype=np.float32) + 0.5, g.standard_normal(C, dtype=np.float32)
     sc1, sh1 = g.random(N1, dtype=np.float32) + 0.5, g.standard_normal(N1, dtype=np.float32)
     want_y = ops.conv2d_nhwc_bf16(t2, w3, 1, 0, sc3, sh3, x, True)
     want_t1 = ops.conv2d_nhwc_bf16(want_y, w1, 1, 0, sc1, sh1, None, True)

@@ -359,8 +359,9 @@ def test_fused_stem_pool_changes_launches_not_results(state50, finch, golden_dir
 
 def test_chained_conv3_conv1_changes_launches_not_results(state50, finch):
     """bf16 fused mode: conv3 of the 64-channel blocks and conv1 of the block after them as one launch
-    (rn_conv_chain_forward_dt, default on) against the separate launches: three ops fewer in
-    ResNet-50 (layer1.0's fused conv3 + downsample pair -> 1.1, layer1.1 -> 1.2, layer1.2 -> layer2.0), the same logits bit for bit, also with two streams and in sub-batches."""
+    (rn_conv_chain_forward_dt, default on) against the separate launches: five ops fewer in
+    ResNet-50 (layer1.0's fused conv3 + downsample pair -> 1.1, layer1.1 -> 1.2, layer1.2 -> layer2.0,
+    layer2.1 -> 2.2, layer2.2 -> 2.3), the same logits bit for bit, also with two streams and in sub-batches."""
     m = R.NativeModel("resnet50", state=state50, dtype="bf16")
     try:
         x = np.concatenate([finch, R.weights.generate_input(130, seed=61)])
@@ -375,8 +376,9 @@ def test_chained_conv3_conv1_changes_launches_not_results(state50, finch):
         assert np.array_equal(chained, plain)
         fused_ops = [l for o, l in ops_chained if o == "conv2d+epilogue+conv2d"]
         assert fused_ops == ["layer1.0.conv3+downsample+next.conv1", "layer1.1.conv3+next.conv1",
-                             "layer1.2.conv3+next.conv1"]
-        assert len(ops_plain) == len(ops_chained) + 3
+                             "layer1.2.conv3+next.conv1", "layer2.1.conv3+next.conv1",
+                             "layer2.2.conv3+next.conv1"]
+        assert len(ops_plain) == len(ops_chained) + 5
         m.set_chain(True)
         m.set_streams(2)
         assert np.array_equal(m.forward(x, fused=True), plain)
