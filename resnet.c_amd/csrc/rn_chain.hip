@@ -297,18 +297,211 @@ void chain_go(rn_ctx *ctx, const ChainParams &p)
     chain_kernel<MID, N1, DUAL><<<dim3(blocks), dim3(64 * Geo<MID>::WAVES), 0, ctx->stream>>>(p);
 }
 
+// ---- fp32 ---------------------------------------------------------------------------------------
+// The same chain with fp32 storage (64 mid channels): 8 waves, 64 rows per step, weights as
+// v_mfma_f32_32x32x2_f32 operands in registers (conv3 32, conv1 128 per lane).  In fp32 both products
+// are matrix-bound (a step is 2 x 8,192 MFMA cycles per SIMD against 7.4 us of HBM time for its 160
+// KB), so what the chain saves is the second launch's own read of y and its ramp.  Differences from
+// the bf16 kernel: the D registers of a lane are four consecutive fp32 channels = 16 bytes already,
+// no lane exchange; the residual tile is fetched INTO the y tile's place in LDS (same operand image)
+// and the epilogue updates it in place, so two 64 KB buffers serve as residual double buffer and y
+// tile; t2 has one buffer, refilled behind the mid-step barrier.  k pairs per MFMA exactly as
+// conv_gemm_kernel<float>: lane half lh holds k = 8ks + 4lh + j for the j-th MFMA of k-step ks.
+constexpr int k32XY = 0, k32XYB = 64 * 1024, k32T2 = 2 * k32XYB, k32T2B = 64 * 256;
+constexpr int k32S = k32T2 + k32T2B, k32Lds = k32S + (512 + 256) * 4;
+
+template <int N1>
+__global__ __launch_bounds__(512) void chain32_kernel(const ChainParams p)
+{
+    constexpr int ROWS = 64, N1F = N1 / 32;
+    __shared__ __attribute__((aligned(16))) char lds[k32Lds];
+    float *const ssl = reinterpret_cast<float *>(lds + k32S);  // sc3[256] sh3[256] sc1[128] sh1[128]
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int nst, s0;
+    {
+        const unsigned total = gridDim.x, v = blockIdx.x;
+        const unsigned base = (unsigned)p.nsteps / total, rem = (unsigned)p.nsteps % total;
+        nst = (int)(base + (v < rem ? 1u : 0u));
+        s0 = (int)(v * base + min(v, rem));
+    }
+    const int pf2 = wave & 1, cf2 = wave >> 1;
+    const bool has2 = cf2 < N1F;  // wave-uniform
+    u32x4 w3r[2][4], w1r[8][4];
+    {
+        const char *r3 = static_cast<const char *>(p.w3) + (size_t)(32 * wave + li) * 256 + lh * 16;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) w3r[kt][ks] = *reinterpret_cast<const u32x4 *>(r3 + kt * 128 + ks * 32);
+        const char *r1 = static_cast<const char *>(p.w1) + (size_t)(32 * (has2 ? cf2 : 0) + li) * 1024 + lh * 16;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) w1r[kt][ks] = *reinterpret_cast<const u32x4 *>(r1 + kt * 128 + ks * 32);
+    }
+    for (int i = t; i < 256; i += 512) {
+        ssl[i] = p.sc3 ? p.sc3[i] : 1.f;
+        ssl[256 + i] = p.sh3 ? p.sh3[i] : -0.f;
+    }
+    for (int i = t; i < N1; i += 512) {
+        ssl[512 + i] = p.sc1 ? p.sc1[i] : 1.f;
+        ssl[640 + i] = p.sh1 ? p.sh1[i] : -0.f;
+    }
+    const i32x4 srd_t2 = make_srd(p.t2, p.t2_bytes);
+    const i32x4 srd_x = make_srd(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_t1 = __builtin_amdgcn_make_buffer_rsrc(p.t1, 0, p.t1_bytes, 0x00020000);
+    const unsigned lds_base = (unsigned)(uintptr_t)((lds_void *)lds);
+    const int prow = lane >> 3, pc = lane & 7;
+
+    // piece q of an operand image with KT 128-byte K tiles per row: K tile q / 8, rows 8(q % 8) ..
+    auto fetch_t2 = [&](int s) {
+        const int m0 = (s0 + s) * ROWS;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = 8 * j + wave, r = 8 * (q & 7) + prow, m = m0 + r;
+            dma16((s < nst && m < p.M) ? m * 256 + (q >> 3) * 128 + ((pc ^ ((r >> 1) & 7)) << 4) : kOob, srd_t2, 0,
+                  lds_base + (unsigned)(k32T2 + q * 1024));
+        }
+    };
+    auto fetch_x = [&](int s, int buf) {
+        const int m0 = (s0 + s) * ROWS;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = 8 * j + wave, r = 8 * (q & 7) + prow, m = m0 + r;
+            dma16((s < nst && m < p.M) ? m * 1024 + (q >> 3) * 128 + ((pc ^ ((r >> 1) & 7)) << 4) : kOob, srd_x, 0,
+                  lds_base + (unsigned)(k32XY + buf * k32XYB + q * 1024));
+        }
+    };
+
+    fetch_t2(0);
+    fetch_x(0, 0);
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        const int m0 = (s0 + s) * ROWS;
+        char *const xy = lds + k32XY + buf * k32XYB;
+        wait_and_barrier<0>();   // t2 and the residual rows of this step are in LDS; everyone is past step s-1
+        fetch_x(s + 1, buf ^ 1);  // (that buffer was step s-1's y tile)
+
+        // ---- conv3: wave w the channels 32w .. 32w+31 of both 32-row fragments ----
+        f32x16 acc[2];
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[pf][e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pf = 0; pf < 2; ++pf) {
+                    const int r = 32 * pf + li;
+                    const u32x4 px = *reinterpret_cast<const u32x4 *>(
+                        lds + k32T2 + kt * 8192 + r * 128 + (((2 * ks + lh) ^ ((r >> 1) & 7)) << 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[pf] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w3r[kt][ks][j]),
+                                                                        __uint_as_float(px[j]), acc[pf], 0, 0, 0);
+                }
+        // lane (li, lh): channels 32w + 8g + 4lh + {0..3}, g = 0..3, of row 32pf + li: chunk 2g + lh of K
+        // tile w of the y tile.  The residual sits there; the result replaces it.
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) {
+            const int r = 32 * pf + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c4 = 32 * wave + 8 * g + 4 * lh;
+                const float4 sc = *reinterpret_cast<const float4 *>(ssl + c4);
+                const float4 sh = *reinterpret_cast<const float4 *>(ssl + 256 + c4);
+                float4 *slot = reinterpret_cast<float4 *>(xy + wave * 8192 + r * 128 + (((2 * g + lh) ^ ((r >> 1) & 7)) << 4));
+                const float4 rv = *slot;
+                float4 o;
+                o.x = fmaxf(fmaf(acc[pf][4 * g], sc.x, sh.x) + rv.x, 0.f);
+                o.y = fmaxf(fmaf(acc[pf][4 * g + 1], sc.y, sh.y) + rv.y, 0.f);
+                o.z = fmaxf(fmaf(acc[pf][4 * g + 2], sc.z, sh.z) + rv.z, 0.f);
+                o.w = fmaxf(fmaf(acc[pf][4 * g + 3], sc.w, sh.w) + rv.w, 0.f);
+                *slot = o;
+            }
+        }
+        __syncthreads();
+        fetch_t2(s + 1);  // every wave has read this step's t2
+
+        // ---- y leaves as whole 1-KB rows (two rounds of four chunks per thread: registers) ----
+#pragma unroll 1
+        for (int i0 = 0; i0 < 8; i0 += 4) {
+#pragma unroll
+            for (int i = i0; i < i0 + 4; ++i) {
+                const int g = t + i * 512, r = g >> 6, c = g & 63, m = m0 + r;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(xy + (c >> 3) * 8192 + r * 128 +
+                                                                 (((c & 7) ^ ((r >> 1) & 7)) << 4));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, m < p.M ? m * 1024 + (c << 4) : kOob, 0, 0);
+            }
+        }
+
+        // ---- conv1 ----
+        if (has2) {
+            const int r = 32 * pf2 + li;
+            f32x16 a2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a2[e] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 px = *reinterpret_cast<const u32x4 *>(
+                        xy + kt * 8192 + r * 128 + (((2 * ks + lh) ^ ((r >> 1) & 7)) << 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w1r[kt][ks][j]), __uint_as_float(px[j]),
+                                                                  a2, 0, 0, 0);
+                }
+            const int m = m0 + r;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c4 = 32 * cf2 + 8 * g + 4 * lh;
+                const float4 sc = *reinterpret_cast<const float4 *>(ssl + 512 + c4);
+                const float4 sh = *reinterpret_cast<const float4 *>(ssl + 640 + c4);
+                u32x4 o;
+                o[0] = __float_as_uint(fmaxf(fmaf(a2[4 * g], sc.x, sh.x), 0.f));
+                o[1] = __float_as_uint(fmaxf(fmaf(a2[4 * g + 1], sc.y, sh.y), 0.f));
+                o[2] = __float_as_uint(fmaxf(fmaf(a2[4 * g + 2], sc.z, sh.z), 0.f));
+                o[3] = __float_as_uint(fmaxf(fmaf(a2[4 * g + 3], sc.w, sh.w), 0.f));
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_t1, m < p.M ? (m * N1 + c4) * 4 : kOob, 0, 0);
+            }
+        }
+    }
+}
+
 int chain_launch(rn_ctx *ctx, const char *what, int dtype, const void *t2, const void *x, bool dual, void *y,
                  const void *w3, const float *scale3, const float *shift3, void *t1, const void *w1,
                  const float *scale1, const float *shift1, uint64_t rows, uint64_t mid_channels,
                  uint64_t channels, uint64_t next_mid)
 {
     if (rows == 0) return RN_OK;
-    RN_REQUIRE(ctx, dtype == RN_DTYPE_BF16, "bf16 storage only");
+    RN_REQUIRE(ctx, dtype == RN_DTYPE_BF16 || dtype == RN_DTYPE_F32, "unknown dtype");
     RN_REQUIRE(ctx, t2 && x && y && w3 && t1 && w1, "null tensor");
     const bool s1 = mid_channels == 64 && channels == 256 && (next_mid == 64 || next_mid == 128);
-    const bool s2 = mid_channels == 128 && channels == 512 && next_mid == 128 && !dual;
-    RN_REQUIRE(ctx, s1 || s2, "shapes: 64 -> 256 -> 64 | 128 channels, or 128 -> 512 -> 128");
-    RN_REQUIRE(ctx, rows * channels * 2 < (1ull << 31), "tensor too large");
+    const bool s2 = mid_channels == 128 && channels == 512 && next_mid == 128 && !dual && dtype == RN_DTYPE_BF16;
+    RN_REQUIRE(ctx, s1 || s2, "shapes: 64 -> 256 -> 64 | 128 channels, or (bf16) 128 -> 512 -> 128");
+    RN_REQUIRE(ctx, !(dual && dtype == RN_DTYPE_F32), "the pair chain exists for bf16 only");
+    const uint64_t es = dtype == RN_DTYPE_BF16 ? 2 : 4;
+    RN_REQUIRE(ctx, rows * channels * es < (1ull << 31), "tensor too large");
+    if (dtype == RN_DTYPE_F32) {
+        ChainParams q;
+        q.t2 = t2, q.x = x, q.y = y, q.w3 = w3, q.sc3 = scale3, q.sh3 = shift3;
+        q.t1 = t1, q.w1 = w1, q.sc1 = scale1, q.sh1 = shift1;
+        q.M = (int)rows;
+        q.nsteps = (int)((rows + 63) / 64);
+        q.t2_bytes = (int)(rows * 256), q.x_bytes = q.y_bytes = (int)(rows * 1024), q.t1_bytes = (int)(rows * next_mid * 4);
+        const dim3 grid(q.nsteps < 256 ? q.nsteps : 256), block(512);
+        if (next_mid == 64)
+            chain32_kernel<64><<<grid, block, 0, ctx->stream>>>(q);
+        else
+            chain32_kernel<128><<<grid, block, 0, ctx->stream>>>(q);
+        return rn_after_launch(ctx, what);
+    }
     ChainParams p;
     p.t2 = t2, p.x = x, p.y = y, p.w3 = w3, p.sc3 = scale3, p.sh3 = shift3;
     p.t1 = t1, p.w1 = w1, p.sc1 = scale1, p.sh1 = shift1;

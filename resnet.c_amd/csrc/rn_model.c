@@ -750,17 +750,17 @@ static int chain_applies(const rn_model *m, const rn_block *b, int mode)
 {
     const int bi = (int)(b - m->blocks);
     const rn_conv *c3 = &m->convs[b->conv3], *n1;
-    if (!m->chain || mode != RN_FWD_FUSED || m->dtype != RN_DTYPE_BF16 || m->recording) return 0;
-    if (b->ds >= 0) { /* first block of a stage: only as the fused pair at equal resolution (stage 1) */
+    if (!m->chain || mode != RN_FWD_FUSED || m->recording) return 0;
+    if (b->ds >= 0) { /* first block of a stage: only as the fused pair at equal resolution (stage 1), bf16 */
         const rn_conv *cd = &m->convs[b->ds];
-        if (!m->pair_fusion || cd->stride != 1 || cd->cin != 64) return 0;
+        if (!m->pair_fusion || cd->stride != 1 || cd->cin != 64 || m->dtype != RN_DTYPE_BF16) return 0;
     }
     if (bi + 1 >= m->n_blocks) return 0;
     if (m->front_parts > 1 && bi + 1 == m->depths[0]) return 0; /* the next block runs in another slice */
     n1 = &m->convs[m->blocks[bi + 1].conv1];
     if (c3->k != 1 || c3->stride != 1 || n1->k != 1 || n1->stride != 1 || n1->cin != c3->cout) return 0;
     if (c3->cin == 64 && c3->cout == 256) return n1->cout == 64 || n1->cout == 128;
-    return c3->cin == 128 && c3->cout == 512 && n1->cout == 128 && b->ds < 0;
+    return m->dtype == RN_DTYPE_BF16 && c3->cin == 128 && c3->cout == 512 && n1->cout == 128 && b->ds < 0;
 }
 
 static int op_chain(rn_model *m, const rn_block *b, const void *t2, const void *shortcut, void *y,

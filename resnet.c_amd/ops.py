@@ -295,6 +295,33 @@ def conv_chain_bf16(t2, x, w3, scale3, shift3, w1, scale1, shift1):
     return yh, th
 
 
+def conv_chain_f32(t2, x, w3, scale3, shift3, w1, scale1, shift1):
+    """rn_conv_chain_forward_dt with fp32 storage (64 -> 256 -> 64 | 128 channels): (y, t1) as NCHW
+    fp32 host arrays."""
+    ctx, lib = get_ctx(), L.lib()
+    B, Cm, H, W = t2.shape
+    C, N1 = w3.shape[0], w1.shape[0]
+    rows = B * H * W
+
+    def pack(w, cin, cout):
+        dw = _up(w, "nchw")
+        pk = FloatTensor((int(lib.rn_conv2d_packed_weight_numel(cin, cout, 1)),), Device.GPU)
+        L.check(lib.rn_conv2d_pack_weight(ctx.handle, dw.data(), pk.data(), cin, cout, 1), "pack", ctx.handle)
+        return pk
+
+    dt2, dx = _up(np.asarray(t2, dtype=np.float32), "nhwc"), _up(np.asarray(x, dtype=np.float32), "nhwc")
+    p3, p1 = pack(w3, Cm, C), pack(w1, C, N1)
+    keep = [_up(np.asarray(v, dtype=np.float32), "nchw") if v is not None else None
+            for v in (scale3, shift3, scale1, shift1)]
+    ptr = [k.data() if k else None for k in keep]
+    y, t1 = FloatTensor((B, C, H, W), Device.GPU), FloatTensor((B, N1, H, W), Device.GPU)
+    L.check(lib.rn_conv_chain_forward_dt(ctx.handle, L.RN_DTYPE_F32, dt2.data(), dx.data(), y.data(), p3.data(),
+                                         ptr[0], ptr[1], t1.data(), p1.data(), ptr[2], ptr[3], rows, Cm, C, N1),
+            "rn_conv_chain_forward_dt", ctx.handle)
+    ctx.sync()
+    return _down(y, (B, C, H, W), "nhwc"), _down(t1, (B, N1, H, W), "nhwc")
+
+
 def conv_chain_pair_bf16(t2, x2, w3, scale3, wd, scaled, shift, w1, scale1, shift1):
     """rn_conv_chain_pair_forward_dt: relu(conv1x1(t2, w3*scale3) + conv1x1(x2, wd*scaled) + shift) -> y
     and relu(bn1(conv1x1(y, w1))) -> t1 as one launch (bf16).  NCHW fp32 host arrays; returns (y, t1)."""

@@ -387,6 +387,30 @@ def test_chained_conv3_conv1_changes_launches_not_results(state50, finch):
         m.close()
 
 
+def test_fp32_chained_conv3_conv1_changes_launches_not_results(state50, finch, golden_dir):
+    """fp32 fused mode: the two 64-channel chains without a downsample branch (layer1.1 -> 1.2,
+    layer1.2 -> layer2.0) as one launch each: two ops fewer, the same logits bit for bit, golden
+    logits held."""
+    m = R.NativeModel("resnet50", state=state50)
+    try:
+        x = np.concatenate([finch, R.weights.generate_input(70, seed=62)])
+        m.set_profiling(True)
+        chained = m.forward(x, fused=True)
+        ops_chained = [(r["op"], r["layer"]) for r in m.profile()]
+        m.set_chain(False)
+        plain = m.forward(x, fused=True)
+        ops_plain = [(r["op"], r["layer"]) for r in m.profile()]
+        m.set_profiling(False)
+        assert np.array_equal(chained, plain)
+        assert [l for o, l in ops_chained if o == "conv2d+epilogue+conv2d"] == \
+            ["layer1.1.conv3+next.conv1", "layer1.2.conv3+next.conv1"]
+        assert len(ops_plain) == len(ops_chained) + 2
+        want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
+        assert np.abs(chained[:1] - want).max() <= TOL
+    finally:
+        m.close()
+
+
 def test_two_stream_forward_under_capture_pipeline_and_shards(state50, finch):
     """bf16 models run a batch of >= 128 images as two halves on two streams (fork / join events).
     The same forward captured as a hipGraph (a cross-stream capture), fed through the host

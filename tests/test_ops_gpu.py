@@ -585,6 +585,30 @@ def test_nchw_route_writes_the_nhwc_routes_bits(case):
         assert np.abs(a - want).max() <= 2e-6 * np.sqrt(Cin * k * k) * float(np.abs(want).max()) + 1e-6
 
 
+@pytest.mark.parametrize("case", [(3, 20, 20, 64), (1, 8, 8, 64), (2, 56, 56, 128), (5, 13, 9, 128)])
+def test_fp32_conv_chain_is_the_two_separate_launches_bit_for_bit(case):
+    """rn_conv_chain_forward_dt, fp32 storage: conv3 + bn3 + residual + ReLU of a 64-channel block and
+    conv1 + bn1 + ReLU of the next as one launch (weights as v_mfma_f32_32x32x2_f32 operands in
+    registers, the residual tile updated in place into the y tile in LDS).  The same k pairs per
+    MFMA and the same epilogue expression as conv_gemm_kernel<float>: y and t1 bit for bit against
+    the two rn_conv2d_nhwc_forward calls, y within tolerance of the oracle."""
+    B, H, W, N1 = case
+    seed = 820 + sum(case)
+    t2, x = rnd((B, 64, H, W), seed), rnd((B, 256, H, W), seed + 1)
+    w3, w1 = rnd((256, 64, 1, 1), seed + 2) / 8.0, rnd((N1, 256, 1, 1), seed + 3) / 16.0
+    g = np.random.default_rng(seed + 4)
+    sc3, sh3 = g.random(256, dtype=np.float32) + 0.5, g.standard_normal(256, dtype=np.float32)
+    sc1, sh1 = g.random(N1, dtype=np.float32) + 0.5, g.standard_normal(N1, dtype=np.float32)
+    want_y = ops.conv2d_nhwc_fused(t2, w3, 1, 0, sc3, sh3, x, True)
+    want_t1 = ops.conv2d_nhwc_fused(want_y, w1, 1, 0, sc1, sh1, None, True)
+    got_y, got_t1 = ops.conv_chain_f32(t2, x, w3, sc3, sh3, w1, sc1, sh1)
+    assert np.array_equal(got_y, want_y)
+    assert np.array_equal(got_t1, want_t1)
+    if B * H * W <= 2000:
+        ref = np.maximum(O.conv2d(t2, w3, 1, 0) * sc3[None, :, None, None] + sh3[None, :, None, None] + x, 0)
+        assert np.abs(got_y - ref).max() <= 2e-5 * float(np.abs(ref).max()) + 1e-6
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 32, 32), (1, 3, 40, 48), (2, 2, 26, 16)])
 @pytest.mark.parametrize("bf16", [False, True])
 def test_fused_stem_and_maxpool_match_the_four_reference_ops(shape, bf16):
