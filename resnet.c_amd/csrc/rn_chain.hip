@@ -474,6 +474,150 @@ __global__ __launch_bounds__(512) void chain32_kernel(const ChainParams p)
     }
 }
 
+// fp32 chain out of the fused conv3 + downsample pair (first block of stage 1): K = 64 + 64 from two
+// tensors, scales folded into the panel, no residual.  With 64 registers for the pair's panel there is
+// no room for conv1's 128, so conv1's weights live in LDS as an operand image (64 KB, fetched once);
+// LDS is then full to the byte (y 64 + w1 64 + t2 16 + second input 16 KB), and the channel
+// constants come from global memory (L1 hits) in the epilogues.
+constexpr int kP32Y = 0, kP32W1 = 64 * 1024, kP32T2 = 128 * 1024, kP32X2 = 144 * 1024, kP32Lds = 160 * 1024;
+
+__global__ __launch_bounds__(512) void chain32_pair_kernel(const ChainParams p)
+{
+    constexpr int ROWS = 64;
+    __shared__ __attribute__((aligned(16))) char lds[kP32Lds];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    int nst, s0;
+    {
+        const unsigned total = gridDim.x, v = blockIdx.x;
+        const unsigned base = (unsigned)p.nsteps / total, rem = (unsigned)p.nsteps % total;
+        nst = (int)(base + (v < rem ? 1u : 0u));
+        s0 = (int)(v * base + min(v, rem));
+    }
+    const int pf2 = wave & 1, cf2 = wave >> 1;
+    const bool has2 = cf2 < 2;  // 64 channels of conv1: four fragments, waves 0-3
+    u32x4 w3r[4][4];            // K tiles 0-1: conv3's rows of the panel, 2-3: the downsample's
+    {
+        const char *r3 = static_cast<const char *>(p.w3) + (size_t)(32 * wave + li) * 512 + lh * 16;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) w3r[kt][ks] = *reinterpret_cast<const u32x4 *>(r3 + kt * 128 + ks * 32);
+    }
+    const i32x4 srd_t2 = make_srd(p.t2, p.t2_bytes);
+    const i32x4 srd_x = make_srd(p.x, p.x_bytes);
+    const i32x4 srd_w1 = make_srd(p.w1, 64 * 256 * 4);
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_t1 = __builtin_amdgcn_make_buffer_rsrc(p.t1, 0, p.t1_bytes, 0x00020000);
+    const unsigned lds_base = (unsigned)(uintptr_t)((lds_void *)lds);
+    const int prow = lane >> 3, pc = lane & 7;
+
+    // conv1's panel [64][256] as an operand image: K tile q / 8, rows 8(q % 8) ..
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = 8 * j + wave, r = 8 * (q & 7) + prow;
+        dma16(r * 1024 + (q >> 3) * 128 + ((pc ^ ((r >> 1) & 7)) << 4), srd_w1, 0,
+              lds_base + (unsigned)(kP32W1 + q * 1024));
+    }
+    auto fetch_in = [&](int s) {  // both 64-channel inputs of step s (one buffer each)
+        const int m0 = (s0 + s) * ROWS;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = 8 * j + wave, r = 8 * (q & 7) + prow, m = m0 + r;
+            const int off = (s < nst && m < p.M) ? m * 256 + (q >> 3) * 128 + ((pc ^ ((r >> 1) & 7)) << 4) : kOob;
+            dma16(off, srd_t2, 0, lds_base + (unsigned)(kP32T2 + q * 1024));
+            dma16(off, srd_x, 0, lds_base + (unsigned)(kP32X2 + q * 1024));
+        }
+    };
+
+    fetch_in(0);
+    for (int s = 0; s < nst; ++s) {
+        const int m0 = (s0 + s) * ROWS;
+        wait_and_barrier<0>();  // this step's inputs are in LDS; everyone is past step s-1 (its y tile is free)
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[pf][e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pf = 0; pf < 2; ++pf) {
+                    const int r = 32 * pf + li;
+                    const u32x4 px = *reinterpret_cast<const u32x4 *>(
+                        lds + (kt < 2 ? kP32T2 : kP32X2) + (kt & 1) * 8192 + r * 128 + (((2 * ks + lh) ^ ((r >> 1) & 7)) << 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[pf] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w3r[kt][ks][j]),
+                                                                        __uint_as_float(px[j]), acc[pf], 0, 0, 0);
+                }
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) {
+            const int r = 32 * pf + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c4 = 32 * wave + 8 * g + 4 * lh;
+                const float4 sh = p.sh3 ? *reinterpret_cast<const float4 *>(p.sh3 + c4) : make_float4(-0.f, -0.f, -0.f, -0.f);
+                float4 o;  // the pair's epilogue: scale folded into the panel, shift, no residual, ReLU
+                o.x = fmaxf(fmaf(acc[pf][4 * g], 1.f, sh.x), 0.f);
+                o.y = fmaxf(fmaf(acc[pf][4 * g + 1], 1.f, sh.y), 0.f);
+                o.z = fmaxf(fmaf(acc[pf][4 * g + 2], 1.f, sh.z), 0.f);
+                o.w = fmaxf(fmaf(acc[pf][4 * g + 3], 1.f, sh.w), 0.f);
+                *reinterpret_cast<float4 *>(lds + kP32Y + wave * 8192 + r * 128 + (((2 * g + lh) ^ ((r >> 1) & 7)) << 4)) = o;
+            }
+        }
+        __syncthreads();
+        fetch_in(s + 1);  // every wave has read this step's inputs
+
+#pragma unroll 1
+        for (int i0 = 0; i0 < 8; i0 += 4) {
+#pragma unroll
+            for (int i = i0; i < i0 + 4; ++i) {
+                const int g = t + i * 512, r = g >> 6, c = g & 63, m = m0 + r;
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + kP32Y + (c >> 3) * 8192 + r * 128 +
+                                                                 (((c & 7) ^ ((r >> 1) & 7)) << 4));
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, m < p.M ? m * 1024 + (c << 4) : kOob, 0, 0);
+            }
+        }
+
+        if (has2) {
+            const int r = 32 * pf2 + li, wr = 32 * cf2 + li;
+            f32x16 a2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a2[e] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x4 px = *reinterpret_cast<const u32x4 *>(
+                        lds + kP32Y + kt * 8192 + r * 128 + (((2 * ks + lh) ^ ((r >> 1) & 7)) << 4));
+                    const u32x4 wv = *reinterpret_cast<const u32x4 *>(
+                        lds + kP32W1 + kt * 8192 + wr * 128 + (((2 * ks + lh) ^ ((wr >> 1) & 7)) << 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wv[j]), __uint_as_float(px[j]), a2, 0, 0, 0);
+                }
+            const int m = m0 + r;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c4 = 32 * cf2 + 8 * g + 4 * lh;
+                const float4 sc = p.sc1 ? *reinterpret_cast<const float4 *>(p.sc1 + c4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float4 sh = p.sh1 ? *reinterpret_cast<const float4 *>(p.sh1 + c4) : make_float4(-0.f, -0.f, -0.f, -0.f);
+                u32x4 o;
+                o[0] = __float_as_uint(fmaxf(fmaf(a2[4 * g], sc.x, sh.x), 0.f));
+                o[1] = __float_as_uint(fmaxf(fmaf(a2[4 * g + 1], sc.y, sh.y), 0.f));
+                o[2] = __float_as_uint(fmaxf(fmaf(a2[4 * g + 2], sc.z, sh.z), 0.f));
+                o[3] = __float_as_uint(fmaxf(fmaf(a2[4 * g + 3], sc.w, sh.w), 0.f));
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_t1, m < p.M ? (m * 64 + c4) * 4 : kOob, 0, 0);
+            }
+        }
+    }
+}
+
 int chain_launch(rn_ctx *ctx, const char *what, int dtype, const void *t2, const void *x, bool dual, void *y,
                  const void *w3, const float *scale3, const float *shift3, void *t1, const void *w1,
                  const float *scale1, const float *shift1, uint64_t rows, uint64_t mid_channels,
@@ -485,7 +629,7 @@ int chain_launch(rn_ctx *ctx, const char *what, int dtype, const void *t2, const
     const bool s1 = mid_channels == 64 && channels == 256 && (next_mid == 64 || next_mid == 128);
     const bool s2 = mid_channels == 128 && channels == 512 && next_mid == 128 && !dual && dtype == RN_DTYPE_BF16;
     RN_REQUIRE(ctx, s1 || s2, "shapes: 64 -> 256 -> 64 | 128 channels, or (bf16) 128 -> 512 -> 128");
-    RN_REQUIRE(ctx, !(dual && dtype == RN_DTYPE_F32), "the pair chain exists for bf16 only");
+    RN_REQUIRE(ctx, !(dual && dtype == RN_DTYPE_F32 && next_mid != 64), "fp32 pair chain: next_mid 64");
     const uint64_t es = dtype == RN_DTYPE_BF16 ? 2 : 4;
     RN_REQUIRE(ctx, rows * channels * es < (1ull << 31), "tensor too large");
     if (dtype == RN_DTYPE_F32) {
@@ -496,7 +640,10 @@ int chain_launch(rn_ctx *ctx, const char *what, int dtype, const void *t2, const
         q.nsteps = (int)((rows + 63) / 64);
         q.t2_bytes = (int)(rows * 256), q.x_bytes = q.y_bytes = (int)(rows * 1024), q.t1_bytes = (int)(rows * next_mid * 4);
         const dim3 grid(q.nsteps < 256 ? q.nsteps : 256), block(512);
-        if (next_mid == 64)
+        if (dual) {
+            q.x_bytes = (int)(rows * 256);
+            chain32_pair_kernel<<<grid, block, 0, ctx->stream>>>(q);
+        } else if (next_mid == 64)
             chain32_kernel<64><<<grid, block, 0, ctx->stream>>>(q);
         else
             chain32_kernel<128><<<grid, block, 0, ctx->stream>>>(q);

@@ -751,9 +751,9 @@ static int chain_applies(const rn_model *m, const rn_block *b, int mode)
     const int bi = (int)(b - m->blocks);
     const rn_conv *c3 = &m->convs[b->conv3], *n1;
     if (!m->chain || mode != RN_FWD_FUSED || m->recording) return 0;
-    if (b->ds >= 0) { /* first block of a stage: only as the fused pair at equal resolution (stage 1), bf16 */
+    if (b->ds >= 0) { /* first block of a stage: only as the fused pair at equal resolution (stage 1) */
         const rn_conv *cd = &m->convs[b->ds];
-        if (!m->pair_fusion || cd->stride != 1 || cd->cin != 64 || m->dtype != RN_DTYPE_BF16) return 0;
+        if (!m->pair_fusion || cd->stride != 1 || cd->cin != 64) return 0;
     }
     if (bi + 1 >= m->n_blocks) return 0;
     if (m->front_parts > 1 && bi + 1 == m->depths[0]) return 0; /* the next block runs in another slice */

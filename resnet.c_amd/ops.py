@@ -322,36 +322,45 @@ def conv_chain_f32(t2, x, w3, scale3, shift3, w1, scale1, shift1):
     return _down(y, (B, C, H, W), "nhwc"), _down(t1, (B, N1, H, W), "nhwc")
 
 
-def conv_chain_pair_bf16(t2, x2, w3, scale3, wd, scaled, shift, w1, scale1, shift1):
+def conv_chain_pair(t2, x2, w3, scale3, wd, scaled, shift, w1, scale1, shift1, bf16: bool = True):
     """rn_conv_chain_pair_forward_dt: relu(conv1x1(t2, w3*scale3) + conv1x1(x2, wd*scaled) + shift) -> y
-    and relu(bn1(conv1x1(y, w1))) -> t1 as one launch (bf16).  NCHW fp32 host arrays; returns (y, t1)."""
+    and relu(bn1(conv1x1(y, w1))) -> t1 as one launch.  NCHW fp32 host arrays; returns (y, t1)."""
     from .tensor import _DeviceBuffer
     ctx, lib = get_ctx(), L.lib()
     B, Cm, H, W = t2.shape
     C, C2, N1 = w3.shape[0], x2.shape[1], w1.shape[0]
     rows = B * H * W
+    dt, es = (L.RN_DTYPE_BF16, 2) if bf16 else (L.RN_DTYPE_F32, 4)
 
     def up_act(a):
-        return _up_raw(to_bf16_bits(np.asarray(a, dtype=np.float32).transpose(0, 2, 3, 1)))
+        a = np.asarray(a, dtype=np.float32).transpose(0, 2, 3, 1)
+        return _up_raw(to_bf16_bits(a) if bf16 else a)
 
     dt2, dx2 = up_act(t2), up_act(x2)
     dw3, dwd, dw1 = _up(w3, "nchw"), _up(wd, "nchw"), _up(w1, "nchw")
     keep = [_up(np.asarray(v, dtype=np.float32), "nchw") if v is not None else None
             for v in (scale3, scaled, shift, scale1, shift1)]
     ptr = [k.data() if k else None for k in keep]
-    pp = _DeviceBuffer(ctx, int(lib.rn_conv2d_packed_pair_weight_numel(Cm, C, 1, C2)) * 2)
-    L.check(lib.rn_conv2d_pack_weight_pair_dt(ctx.handle, L.RN_DTYPE_BF16, dw3.data(), ptr[0], dwd.data(), ptr[1],
+    pp = _DeviceBuffer(ctx, int(lib.rn_conv2d_packed_pair_weight_numel(Cm, C, 1, C2)) * es)
+    L.check(lib.rn_conv2d_pack_weight_pair_dt(ctx.handle, dt, dw3.data(), ptr[0], dwd.data(), ptr[1],
                                               pp.ptr, Cm, C, 1, C2), "pack_pair", ctx.handle)
-    p1 = _DeviceBuffer(ctx, int(lib.rn_conv2d_packed_weight_numel_dt(L.RN_DTYPE_BF16, C, N1, 1)) * 2)
-    L.check(lib.rn_conv2d_pack_weight_dt(ctx.handle, L.RN_DTYPE_BF16, dw1.data(), p1.ptr, C, N1, 1), "pack_dt", ctx.handle)
-    y, t1 = _DeviceBuffer(ctx, rows * C * 2), _DeviceBuffer(ctx, rows * N1 * 2)
-    L.check(lib.rn_conv_chain_pair_forward_dt(ctx.handle, L.RN_DTYPE_BF16, dt2.ptr, dx2.ptr, y.ptr, pp.ptr, ptr[2],
+    p1 = _DeviceBuffer(ctx, int(lib.rn_conv2d_packed_weight_numel_dt(dt, C, N1, 1)) * es)
+    L.check(lib.rn_conv2d_pack_weight_dt(ctx.handle, dt, dw1.data(), p1.ptr, C, N1, 1), "pack_dt", ctx.handle)
+    y, t1 = _DeviceBuffer(ctx, rows * C * es), _DeviceBuffer(ctx, rows * N1 * es)
+    L.check(lib.rn_conv_chain_pair_forward_dt(ctx.handle, dt, dt2.ptr, dx2.ptr, y.ptr, pp.ptr, ptr[2],
                                               t1.ptr, p1.ptr, ptr[3], ptr[4], rows, Cm, C2, C, N1),
             "rn_conv_chain_pair_forward_dt", ctx.handle)
     ctx.sync()
-    yh = from_bf16_bits(_down_raw(y, np.uint16, rows * C)).reshape(B, H, W, C).transpose(0, 3, 1, 2).copy()
-    th = from_bf16_bits(_down_raw(t1, np.uint16, rows * N1)).reshape(B, H, W, N1).transpose(0, 3, 1, 2).copy()
-    return yh, th
+
+    def down(b, n, c):
+        h = from_bf16_bits(_down_raw(b, np.uint16, n)) if bf16 else _down_raw(b, np.float32, n)
+        return h.reshape(B, H, W, c).transpose(0, 3, 1, 2).copy()
+
+    return down(y, rows * C, C), down(t1, rows * N1, N1)
+
+
+def conv_chain_pair_bf16(*a):
+    return conv_chain_pair(*a, bf16=True)
 
 
 def conv2d_nhwc_pair(x, w, x2, w2, stride=1, pad=0, stride2=1, scale=None, scale2=None, shift=None,

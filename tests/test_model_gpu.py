@@ -388,8 +388,8 @@ def test_chained_conv3_conv1_changes_launches_not_results(state50, finch):
 
 
 def test_fp32_chained_conv3_conv1_changes_launches_not_results(state50, finch, golden_dir):
-    """fp32 fused mode: the two 64-channel chains without a downsample branch (layer1.1 -> 1.2,
-    layer1.2 -> layer2.0) as one launch each: two ops fewer, the same logits bit for bit, golden
+    """fp32 fused mode: the three chains of the 64-channel blocks (layer1.0's pair -> 1.1, layer1.1 -> 1.2,
+    layer1.2 -> layer2.0) as one launch each: three ops fewer, the same logits bit for bit, golden
     logits held."""
     m = R.NativeModel("resnet50", state=state50)
     try:
@@ -403,8 +403,8 @@ def test_fp32_chained_conv3_conv1_changes_launches_not_results(state50, finch, g
         m.set_profiling(False)
         assert np.array_equal(chained, plain)
         assert [l for o, l in ops_chained if o == "conv2d+epilogue+conv2d"] == \
-            ["layer1.1.conv3+next.conv1", "layer1.2.conv3+next.conv1"]
-        assert len(ops_plain) == len(ops_chained) + 2
+            ["layer1.0.conv3+downsample+next.conv1", "layer1.1.conv3+next.conv1", "layer1.2.conv3+next.conv1"]
+        assert len(ops_plain) == len(ops_chained) + 3
         want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
         assert np.abs(chained[:1] - want).max() <= TOL
     finally:

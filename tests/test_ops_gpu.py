@@ -609,6 +609,27 @@ def test_fp32_conv_chain_is_the_two_separate_launches_bit_for_bit(case):
         assert np.abs(got_y - ref).max() <= 2e-5 * float(np.abs(ref).max()) + 1e-6
 
 
+@pytest.mark.parametrize("case", [(3, 20, 20), (2, 56, 56), (1, 9, 7)])
+def test_fp32_conv_chain_out_of_the_fused_pair_bit_for_bit(case):
+    """rn_conv_chain_pair_forward_dt, fp32: the fused conv3 + downsample pair as the chain's first
+    product (conv1's panel as an operand image in LDS), against rn_conv2d_nhwc_pair_forward_dt
+    followed by the next block's conv1."""
+    B, H, W = case
+    seed = 860 + sum(case)
+    t2, x2 = rnd((B, 64, H, W), seed), rnd((B, 64, H, W), seed + 1)
+    w3, wd = rnd((256, 64, 1, 1), seed + 2) / 8.0, rnd((256, 64, 1, 1), seed + 3) / 8.0
+    w1 = rnd((64, 256, 1, 1), seed + 4) / 16.0
+    g = np.random.default_rng(seed + 5)
+    sc3, scd = g.random(256, dtype=np.float32) + 0.5, g.random(256, dtype=np.float32) + 0.5
+    shift = g.standard_normal(256, dtype=np.float32)
+    sc1, sh1 = g.random(64, dtype=np.float32) + 0.5, g.standard_normal(64, dtype=np.float32)
+    want_y = ops.conv2d_nhwc_pair(t2, w3, x2, wd, 1, 0, 1, sc3, scd, shift, None, True)
+    want_t1 = ops.conv2d_nhwc_fused(want_y, w1, 1, 0, sc1, sh1, None, True)
+    got_y, got_t1 = ops.conv_chain_pair(t2, x2, w3, sc3, wd, scd, shift, w1, sc1, sh1, bf16=False)
+    assert np.array_equal(got_y, want_y)
+    assert np.array_equal(got_t1, want_t1)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 32, 32), (1, 3, 40, 48), (2, 2, 26, 16)])
 @pytest.mark.parametrize("bf16", [False, True])
 def test_fused_stem_and_maxpool_match_the_four_reference_ops(shape, bf16):
