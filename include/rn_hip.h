@@ -332,11 +332,11 @@ RN_API int rn_stem_pool_nchw_forward_dt(rn_ctx *ctx, int dtype, const float *inp
                                         const float *shift, int relu, uint64_t B,
                                         uint64_t in_channels, uint64_t H, uint64_t W);
 /* conv3 + bn3 + residual add + ReLU of one bottleneck block and conv1 + bn1 + ReLU of the next
- * (layerForward, main.cu:131-164, end of one pass and start of the next) as ONE launch on bf16
- * NHWC tensors: t2 [rows][mid] -> y [rows][channels] (written: the next block's residual) ->
+ * (layerForward, main.cu:131-164, end of one pass and start of the next) as ONE launch on bf16 or
+ * fp32 NHWC tensors: t2 [rows][mid] -> y [rows][channels] (written: the next block's residual) ->
  * t1 [rows][next_mid]; y reaches conv1 through LDS instead of HBM.  The same bits as the two
- * separate rn_conv2d_nhwc_forward_dt calls.  (mid, channels, next_mid) = (64, 256, 64 | 128) or
- * (128, 512, 128); packed weights from rn_conv2d_pack_weight_dt; scale/shift may be NULL. */
+ * separate rn_conv2d_nhwc_forward_dt calls.  (mid, channels, next_mid) = (64, 256, 64 | 128) or, bf16
+ * only, (128, 512, 128); packed weights from rn_conv2d_pack_weight_dt; scale/shift may be NULL. */
 RN_API int rn_conv_chain_forward_dt(rn_ctx *ctx, int dtype, const void *t2, const void *residual,
                                     void *y, const void *packed_w3, const float *scale3,
                                     const float *shift3, void *t1, const void *packed_w1,
@@ -345,14 +345,14 @@ RN_API int rn_conv_chain_forward_dt(rn_ctx *ctx, int dtype, const void *t2, cons
 /* The same chain out of the fused conv3 + downsample pair of a stage's first block
  * (rn_conv2d_nhwc_pair_forward_dt: panel from rn_conv2d_pack_weight_pair_dt with the scales folded
  * in, K = mid + in2 channels, no residual): y = relu(t2 . w3s + x2 . wds + shift), then conv1.
- * in2_channels 64. */
+ * in2_channels 64; fp32: next_mid 64. */
 RN_API int rn_conv_chain_pair_forward_dt(rn_ctx *ctx, int dtype, const void *t2, const void *x2,
                                          void *y, const void *packed_pair, const float *shift,
                                          void *t1, const void *packed_w1, const float *scale1,
                                          const float *shift1, uint64_t rows, uint64_t mid_channels,
                                          uint64_t in2_channels, uint64_t channels, uint64_t next_mid);
-/* Fused bf16 mode: conv3 of a 64-channel block and conv1 of the block after it as one launch
- * (rn_conv_chain_forward_dt; default on).  The same bits either way. */
+/* Fused mode: conv3 of a block and conv1 of the block after it as one launch where a chain kernel
+ * exists (rn_conv_chain_forward_dt; default on).  The same bits either way. */
 RN_API int rn_model_set_chain(rn_model *m, int on);
 /* Fused mode: use it for conv1 + bn1 + relu + maxpool (default on; fp32 needs the exact-K stem
  * image, rn_model_set_stem_exact).  on == 2: through rn_stem_pool_nchw_forward_dt, the input
