@@ -576,16 +576,18 @@ def test_pair_fusion_changes_launches_not_results(model50, finch):
     launches fewer, same logits within the fold's rounding, same top-1."""
     x = R.weights.generate_input(3, seed=77)
     x[0] = finch[0]
-    with_pair = model50.forward(x, fused=True)
-    model50.set_profiling(True)
-    model50.forward(x, fused=True)
-    n_pair = len(model50.profile())
-    model50.set_pair_fusion(False)
+    model50.set_chain(False)   # (the stage-1 pair would otherwise carry the next conv1 as well)
     try:
+        with_pair = model50.forward(x, fused=True)
+        model50.set_profiling(True)
+        model50.forward(x, fused=True)
+        n_pair = len(model50.profile())
+        model50.set_pair_fusion(False)
         without = model50.forward(x, fused=True)
         n_plain = len(model50.profile())
     finally:
         model50.set_pair_fusion(True)
+        model50.set_chain(True)
         model50.set_profiling(False)
     assert n_plain - n_pair == 4
     assert np.abs(with_pair - without).max() <= 2e-5
