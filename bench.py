@@ -365,7 +365,7 @@ def main():
                      "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                      "frac": round(max(frac_mfma, frac_hbm), 4),
                      "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "conv_gemm_kernel" + (" / conv_wide_kernel / conv_strip_kernel / chain_kernel" if args.dtype == "bf16" else "") +
+                     "kernel": "conv_gemm_kernel" + (" / conv_wide_kernel / conv_strip_kernel / chain_kernel" if args.dtype == "bf16" else " / chain32_kernel") +
                                " (implicit-GEMM conv2d + fc on " +
                                ("v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else "v_mfma_f32_32x32x16_bf16)"),
                      "mfma_TFLOPs": round(achieved, 2), "mfma_frac": round(frac_mfma, 4),

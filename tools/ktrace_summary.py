@@ -20,7 +20,7 @@ def family(name):
         return "stem_pool_kernel"
     if "conv_strip_kernel" in name:
         return "conv_strip_kernel"
-    if "chain_kernel" in name:
+    if "chain_kernel" in name or "chain32_" in name:
         return "chain_kernel"
     if "maxpool3_nhwc_kernel" in name:
         return "maxpool3_nhwc_kernel"

@@ -26,8 +26,9 @@ def main():
                     short = fam + name.split(fam)[1].split(">")[0] + ">"
             if "conv_strip_kernel" in name:
                 short = "conv_strip_kernel"
-            if "chain_kernel" in name:
-                short = "chain_kernel" + name.split("chain_kernel")[1].split("E")[0]
+            for fam in ("chain_kernel", "chain32_kernel", "chain32_pair_kernel"):
+                if fam in name:
+                    short = fam + name.split(fam)[1].split("(")[0]
             agg[short][r["Counter_Name"]] += float(r["Counter_Value"])
             key = (f, r["Dispatch_Id"])
             if key not in seen:
