@@ -428,15 +428,23 @@ __global__ __launch_bounds__(512) void chain32_kernel(const ChainParams p)
         __syncthreads();
         fetch_t2(s + 1);  // every wave has read this step's t2
 
-        // ---- y leaves as whole 1-KB rows (two rounds of four chunks per thread: registers) ----
+        // ---- y leaves as whole 1-KB rows (rounds of four chunks per thread: registers).  With 64
+        // channels in conv1 only waves 0-3 have a fragment of it: the other four carry y out alone
+        // and conv1 starts at once ----
+        {
+            constexpr bool kSplit = N1F == 2;
+            const int tt = kSplit ? t - 256 : t;
+            if (!kSplit || wave >= 4) {
 #pragma unroll 1
-        for (int i0 = 0; i0 < 8; i0 += 4) {
+                for (int i0 = 0; i0 < (kSplit ? 16 : 8); i0 += 4) {
 #pragma unroll
-            for (int i = i0; i < i0 + 4; ++i) {
-                const int g = t + i * 512, r = g >> 6, c = g & 63, m = m0 + r;
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(xy + (c >> 3) * 8192 + r * 128 +
-                                                                 (((c & 7) ^ ((r >> 1) & 7)) << 4));
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, m < p.M ? m * 1024 + (c << 4) : kOob, 0, 0);
+                    for (int i = i0; i < i0 + 4; ++i) {
+                        const int g = tt + i * (kSplit ? 256 : 512), r = g >> 6, c = g & 63, m = m0 + r;
+                        const u32x4 v = *reinterpret_cast<const u32x4 *>(xy + (c >> 3) * 8192 + r * 128 +
+                                                                         (((c & 7) ^ ((r >> 1) & 7)) << 4));
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, m < p.M ? m * 1024 + (c << 4) : kOob, 0, 0);
+                    }
+                }
             }
         }
 
@@ -573,14 +581,16 @@ __global__ __launch_bounds__(512) void chain32_pair_kernel(const ChainParams p)
         __syncthreads();
         fetch_in(s + 1);  // every wave has read this step's inputs
 
+        if (wave >= 4) {  // waves 0-3 go straight to conv1; these four carry y out
 #pragma unroll 1
-        for (int i0 = 0; i0 < 8; i0 += 4) {
+            for (int i0 = 0; i0 < 16; i0 += 4) {
 #pragma unroll
-            for (int i = i0; i < i0 + 4; ++i) {
-                const int g = t + i * 512, r = g >> 6, c = g & 63, m = m0 + r;
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + kP32Y + (c >> 3) * 8192 + r * 128 +
-                                                                 (((c & 7) ^ ((r >> 1) & 7)) << 4));
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, m < p.M ? m * 1024 + (c << 4) : kOob, 0, 0);
+                for (int i = i0; i < i0 + 4; ++i) {
+                    const int g = t - 256 + i * 256, r = g >> 6, c = g & 63, m = m0 + r;
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + kP32Y + (c >> 3) * 8192 + r * 128 +
+                                                                     (((c & 7) ^ ((r >> 1) & 7)) << 4));
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_y, m < p.M ? m * 1024 + (c << 4) : kOob, 0, 0);
+                }
             }
         }
 
