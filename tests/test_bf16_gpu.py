@@ -274,6 +274,59 @@ def test_conv_chain_out_of_the_fused_pair_bit_for_bit(case):
     assert np.array_equal(got_t1, want_t1)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_chain_kernels_full_size_under_load(dtype):
+    """The chained launches order their LDS double buffers with one vmcnt(0) + barrier per step and a
+    second barrier before the y tile is read.  A read that slipped ahead of its DMA would show as rare
+    wrong rows that come and go with timing: the stage-1 shape at B = 96 (4,704 steps of 64 rows, 18
+    per block) many times back to back on device-resident buffers, every run held to the two
+    separate launches' bits."""
+    from resnet_c_amd import _lib as L
+    from resnet_c_amd.tensor import _DeviceBuffer
+    ctx, lib = R.get_ctx(), L.lib()
+    B, H, W, N1 = 96, 56, 56, 64
+    rows = B * H * W
+    bf = dtype == "bf16"
+    dt, es = (L.RN_DTYPE_BF16, 2) if bf else (L.RN_DTYPE_F32, 4)
+    g = np.random.default_rng(5)
+
+    def buf(n, scale):
+        h = g.standard_normal(n, dtype=np.float32) * scale
+        h = ops.to_bf16_bits(h) if bf else h
+        b = _DeviceBuffer(ctx, n * es)
+        L.check(lib.rn_memcpy_h2d(ctx.handle, b.ptr, h.ctypes.data, h.nbytes), "h2d", ctx.handle)
+        return b
+
+    t2, x = buf(rows * 64, 0.5), buf(rows * 256, 0.5)
+    w3, w1 = buf(256 * 64, 0.12), buf(N1 * 256, 0.06)   # 1x1 panels: the packed layout is [Cout][Cin]
+    y, t1 = _DeviceBuffer(ctx, rows * 256 * es), _DeviceBuffer(ctx, rows * N1 * es)
+    one = R.FloatTensor.from_numpy(np.full(256, 0.75, np.float32), R.Device.GPU)
+    ep3, ep1 = L.Epilogue(one.data(), one.data(), x.ptr, 1), L.Epilogue(one.data(), one.data(), None, 1)
+
+    def fetch():
+        ctx.sync()
+        a, b = np.empty(rows * 256 * es, np.uint8), np.empty(rows * N1 * es, np.uint8)
+        L.check(lib.rn_memcpy_d2h(ctx.handle, a.ctypes.data, y.ptr, a.nbytes), "d2h", ctx.handle)
+        L.check(lib.rn_memcpy_d2h(ctx.handle, b.ctypes.data, t1.ptr, b.nbytes), "d2h", ctx.handle)
+        return a, b
+
+    L.check(lib.rn_conv2d_nhwc_forward_dt(ctx.handle, dt, dt, t2.ptr, y.ptr, w3.ptr, 1, 1, 0, H, W, B, 64, 256, H, W,
+                                          ctypes.byref(ep3)), "conv3", ctx.handle)
+    L.check(lib.rn_conv2d_nhwc_forward_dt(ctx.handle, dt, dt, y.ptr, t1.ptr, w1.ptr, 1, 1, 0, H, W, B, 256, N1, H, W,
+                                          ctypes.byref(ep1)), "conv1", ctx.handle)
+    want_y, want_t1 = fetch()
+    assert want_t1.any()
+    for rep in range(6):
+        L.check(lib.rn_memset(ctx.handle, y.ptr, 0xFF, rows * 256 * es), "memset", ctx.handle)
+        L.check(lib.rn_memset(ctx.handle, t1.ptr, 0xFF, rows * N1 * es), "memset", ctx.handle)
+        for _ in range(5):
+            L.check(lib.rn_conv_chain_forward_dt(ctx.handle, dt, t2.ptr, x.ptr, y.ptr, w3.ptr, one.data(), one.data(),
+                                                 t1.ptr, w1.ptr, one.data(), one.data(), rows, 64, 256, N1),
+                    "chain", ctx.handle)
+        got_y, got_t1 = fetch()
+        assert np.array_equal(got_y, want_y) and np.array_equal(got_t1, want_t1), rep
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_wide_kernel_random_shapes_against_the_4_wave_kernel(seed):
     """Random geometry (image size, stride, padding, channel counts that leave ragged M and N
