@@ -411,6 +411,21 @@ def test_fp32_chained_conv3_conv1_changes_launches_not_results(state50, finch, g
         m.close()
 
 
+@pytest.mark.parametrize("arch", ["resnet101", "resnet152"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_chains_in_the_deeper_networks(arch, dtype):
+    """The chained launches in ResNet-101 / -152 (the same three of stage 1; bf16: every 128-channel
+    boundary of the longer stage 2 as well): the same logits with and without, bit for bit."""
+    m = R.NativeModel(arch, state=R.weights.generate_state(arch, seed=3), dtype=dtype)
+    try:
+        x = R.weights.generate_input(70, seed=4)
+        chained = m.forward(x, fused=True)
+        m.set_chain(False)
+        assert np.array_equal(chained, m.forward(x, fused=True)) and np.isfinite(chained).all()
+    finally:
+        m.close()
+
+
 def test_two_stream_forward_under_capture_pipeline_and_shards(state50, finch):
     """bf16 models run a batch of >= 128 images as two halves on two streams (fork / join events).
     The same forward captured as a hipGraph (a cross-stream capture), fed through the host
