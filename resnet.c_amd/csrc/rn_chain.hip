@@ -177,7 +177,9 @@ __global__ __launch_bounds__(64 * Geo<MID>::WAVES) void chain_kernel(const Chain
         // this step's rows have landed (and the previous step's stores are out), all waves are past
         // the previous step: its buffers take the next step's rows
         wait_and_barrier<0>();
-        fetch(s + 1, buf ^ 1);
+        // With one wave per SIMD (MID 128) the ten DMA issues would stand in front of the step's first
+        // MFMA: they go out behind the first product instead (they still have the rest of the step)
+        if constexpr (MID == 64) fetch(s + 1, buf ^ 1);
 
         // ---- first product: y[ROWS][C] = t2[ROWS][MID] . w3^T (+ second input . wd^T) ----
         f32x16 acc[PF][CF1];
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(64 * Geo<MID>::WAVES) void chain_kernel(const Chain
                                                                          __builtin_bit_cast(bf16x8, px), acc[pf][f], 0, 0, 0);
             }
         }
+        if constexpr (MID != 64) fetch(s + 1, buf ^ 1);
         // lane (li, lh): channels 32cf + 8j + 4lh + {0..3}, j = 0..3, of row 32pf + li.  Affine,
         // residual (8 bytes from the swizzled LDS rows), ReLU, bf16; the half-waves trade groups so
         // that each lane owns 8 consecutive channels = one 16-byte chunk of the y tile.
