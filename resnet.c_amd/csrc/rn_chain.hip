@@ -394,12 +394,14 @@ __global__ __launch_bounds__(512) void chain32_kernel(const ChainParams p)
         for (int pf = 0; pf < 2; ++pf)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[pf][e] = 0.f;
+        // (fragment-major: the first fragment's accumulators are final while the second is still being
+        // multiplied, so its epilogue below can be scheduled among those MFMAs)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int pf = 0; pf < 2; ++pf)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int pf = 0; pf < 2; ++pf) {
+                for (int ks = 0; ks < 4; ++ks) {
                     const int r = 32 * pf + li;
                     const u32x4 px = *reinterpret_cast<const u32x4 *>(
                         lds + k32T2 + kt * 8192 + r * 128 + (((2 * ks + lh) ^ ((r >> 1) & 7)) << 4));
@@ -553,11 +555,11 @@ __global__ __launch_bounds__(512) void chain32_pair_kernel(const ChainParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[pf][e] = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int pf = 0; pf < 2; ++pf)  // fragment-major, as in chain32_kernel
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int pf = 0; pf < 2; ++pf) {
+                for (int ks = 0; ks < 4; ++ks) {
                     const int r = 32 * pf + li;
                     const u32x4 px = *reinterpret_cast<const u32x4 *>(
                         lds + (kt < 2 ? kP32T2 : kP32X2) + (kt & 1) * 8192 + r * 128 + (((2 * ks + lh) ^ ((r >> 1) & 7)) << 4));
