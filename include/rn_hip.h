@@ -274,9 +274,8 @@ RN_API int rn_model_set_stem_exact(rn_model *m, int on);
 /* streams = 1, 2 or 4: a (sub-)batch runs as that many contiguous parts (of at least 64 images
  * each) on streams of their own -- the launches of one part fill the tails of the others';
  * every image's logits are independent of what else is in its launch, so no bit changes.
- * Default: 1 for fp32 models (measured +0.5 %), 2 for bf16 storage (+9 %: its 256-wide tiles
- * leave CUs idle in the late stages); rn_model_set_dtype applies the default unless this was
- * called.  Profiled and tuning forwards always use one stream.  Changing it invalidates the
+ * Default: 2 (measured at B = 256: fp32 +0.8 %, bf16 storage +5..9 %: its 256-wide tiles leave
+ * CUs idle in the late stages).  Profiled and tuning forwards always use one stream.  Changing it invalidates the
  * tuned tiles. */
 RN_API int rn_model_set_streams(rn_model *m, int streams);
 RN_API int rn_model_get_streams(const rn_model *m);

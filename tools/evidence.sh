@@ -9,6 +9,7 @@ mkdir -p $o
 export TMPDIR=/tmp
 if [ $what = bench ] || [ $what = all ]; then
   python bench.py > $o/bench_f32.json 2> $o/bench_f32.err
+  python bench.py --streams 1 --no-cpu-baseline --no-pipeline > $o/bench_f32_one_stream.json 2> $o/bench_f32_1s.err
   python bench.py --dtype bf16 --no-cpu-baseline --no-pipeline > $o/bench_bf16.json 2> $o/bench_bf16.err
   python bench.py --dtype bf16 --streams 1 --no-cpu-baseline --no-pipeline > $o/bench_bf16_one_stream.json 2> $o/bench_bf16_1s.err
   python bench.py --arch resnet152 --batch 128 --no-cpu-baseline --no-pipeline > $o/bench_resnet152_b128.json 2> $o/bench_resnet152.err
