@@ -692,6 +692,197 @@ __global__ __launch_bounds__(512, 2) void conv_strip_kernel(const StripParams p)
     }
 }
 
+
+// ---- the strip kernel for 128 -> 128 channels (conv2 of the second stage) ----
+//
+// The same construction with K = 1,152: a 32-channel fragment's weights are 72 k-steps x 4 = 288
+// registers, which only a wave that has its SIMD to itself can hold -- so 4 waves per block, one per
+// SIMD, 512 registers each; wave w owns output channels 32w .. 32w+31 and multiplies ALL of a step's
+// 128 positions (four fragments, four independent accumulators).  The ring holds the two 128-byte
+// channel segments of a position as two images of 320 positions.  The weights (295 KB) pass through
+// LDS in two halves before the ring is in use.
+constexpr int kRing2 = 320, kMargin2 = 32, kSeg2 = kRing2 * 128;  // W + 3 <= 32
+
+__global__ __launch_bounds__(256) void conv_strip128_kernel(const StripParams p)
+{
+    __shared__ __attribute__((aligned(16))) char lds[64 * 145 * 16];  // >= 2 * kSeg2: weight staging is the larger
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int prow = lane >> 3, pc = lane & 7;
+    stamp(p.stamps, 0);
+    int nst, ub;
+    {
+        const unsigned total = gridDim.x, v = blockIdx.x;
+        const unsigned q = total >> 3, r = total & 7, xcd = v & 7;
+        const unsigned logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        const unsigned base = (unsigned)p.nsteps / total, rem = (unsigned)p.nsteps % total;
+        nst = (int)(base + (logical < rem ? 1u : 0u));
+        ub = (int)(logical * base + min(logical, rem)) * 128;
+    }
+    const i32x4 srd_in = make_srd(p.in, p.in_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+    const unsigned lds_base = (unsigned)(uintptr_t)((lds_void *)lds);
+
+    // weights: two rounds of 64 output channels; LDS rows of 145 chunks (144 + 1: 145r mod 16 differs
+    // for the 16 rows of a ds_read_b128 lane group)
+    i32x4 wreg[72];
+    {
+        const i32x4 srd_w = make_srd(p.w, 128 * 1152 * 2);
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            if (round) __syncthreads();  // the first half has been picked up
+#pragma unroll 1
+            for (int q = wave; q < 145; q += 4) {  // 64 rows x 145 chunks = 145 pieces of 64 chunks
+                const int pos = q * 64 + lane, r = (pos * 3616) >> 19, c = pos - r * 145;  // pos / 145, pos < 9,280
+                dma16(c < 144 ? ((64 * round + r) * 144 + c) * 16 : kOob, srd_w, 0,
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(q * 1024))));
+            }
+            wait_and_barrier<0>();
+            if ((wave >> 1) == round) {
+                const char *wrow = lds + (32 * (wave & 1) + li) * (145 * 16) + lh * 16;
+#pragma unroll
+                for (int s = 0; s < 72; ++s) wreg[s] = *reinterpret_cast<const i32x4 *>(wrow + s * 32);
+            }
+        }
+        __syncthreads();
+    }
+    stamp(p.stamps, 1);
+    // channel constants of this lane's 16 output channels (D map: 32w + 8j + 4lh + {0..3})
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c4 = 32 * wave + 8 * j + 4 * lh;
+        sc[j] = p.scale ? *reinterpret_cast<const float4 *>(p.scale + c4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[j] = p.shift ? *reinterpret_cast<const float4 *>(p.shift + c4) : make_float4(-0.f, -0.f, -0.f, -0.f);
+    }
+
+    auto pixel_of = [&](int u) -> int {
+        if (u < 0 || u >= p.U) return -1;
+        const unsigned R = __umulhi((unsigned)u, p.mul_wp) >> p.shr_wp;
+        const int cc = u - (int)R * p.Wp;
+        const unsigned b = __umulhi(R, p.mul_hq) >> p.shr_hq;
+        const int rr = (int)R - (int)b * p.Hq;
+        if (cc < 1 || cc > p.W || rr < 1) return -1;
+        return ((int)b * p.H + rr - 1) * p.W + cc - 1;
+    };
+    // piece of 8 ring positions starting at ring position slot0, channel segment seg
+    auto src_off = [&](int u, int slot, int seg) -> int {
+        const int g = pixel_of(u);
+        return g < 0 ? kOob : g * 256 + seg * 128 + ((pc ^ ((slot >> 1) & 7)) << 4);
+    };
+    // ring positions 0 .. 191 = padded positions ub - 32 .. ub + 159: all of step 0's; 48 pieces
+#pragma unroll 1
+    for (int q = wave; q < 48; q += 4) {
+        const int seg = q / 24, slot = 8 * (q % 24) + prow;
+        dma16(src_off(ub - kMargin2 + slot, slot, seg), srd_in, 0,
+              (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + (unsigned)(seg * kSeg2 + (q % 24) * 1024))));
+    }
+
+    i32x4 pend[4][2];
+    int pend_off[4] = {kOob, kOob, kOob, kOob};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pend[i][0] = pend[i][1] = i32x4{0, 0, 0, 0};
+    auto store_piece = [&](int q) {
+        const int i = q >> 1, h = q & 1;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[i][h]), rsrc_o,
+                                               pend_off[i] == kOob ? kOob : pend_off[i] + 32 * h, 0, 0);
+    };
+
+    int relbase = 0;  // (128 * s) mod 320
+    for (int s = 0; s < nst; ++s) {
+        wait_and_barrier<0>();
+        if (s == 0) stamp(p.stamps, 2);
+        if (s == 1) stamp(p.stamps, 5);
+        // next step's 128 positions: 32 pieces (2 segments x 16), eight per wave, issued among the MFMAs
+        int nxt_off[8];
+        unsigned nxt_dst[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = 4 * j + wave, seg = q >> 4, g8 = q & 15;
+            int slot0 = relbase + 192 + 8 * g8;
+            slot0 = slot0 >= kRing2 ? slot0 - kRing2 : slot0;
+            const int u = ub - kMargin2 + 128 * s + 192 + 8 * g8 + prow;
+            nxt_off[j] = s + 1 < nst ? src_off(u, slot0 + prow, seg) : kOob;
+            nxt_dst[j] = lds_base + (unsigned)(seg * kSeg2 + slot0 * 128);
+        }
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+        // 288 (fragment read, MFMA) pairs: n = 4 * kstep + i, kstep = (tap * 2 + seg) * 4 + ks; reads kDepth
+        // pairs ahead through a ring of fragment registers, pinned where they are written
+        constexpr int kDepth = 8;
+        i32x4 px[kDepth];
+        int y[9][4];
+        auto read = [&](int n) -> i32x4 {
+            const int i = n & 3, kstep = n >> 2, ks = kstep & 3, seg = (kstep >> 2) & 1, tap = kstep >> 3;
+            if (ks == 0 && seg == 0) {
+                const int shift = (tap / 3 - 1) * p.Wp + (tap % 3 - 1);
+                int sb = relbase + kMargin2 + 32 * i + shift;  // scalar, >= 0
+                sb = sb >= kRing2 ? sb - kRing2 : sb;
+                const unsigned r0 = (unsigned)(sb + li);
+                const unsigned r = min(r0, r0 - (unsigned)kRing2);
+                y[tap][i] = (int)((r << 7) | (((unsigned)lh ^ ((r >> 1) & 7u)) << 4));
+            }
+            return *reinterpret_cast<const i32x4 *>(lds + seg * kSeg2 + (y[tap][i] ^ (ks << 5)));
+        };
+#pragma unroll
+        for (int n = 0; n < kDepth; ++n) px[n] = read(n);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < 288; ++n) {
+            acc[n & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[n >> 2]),
+                                                                 __builtin_bit_cast(bf16x8, px[n % kDepth]),
+                                                                 acc[n & 3], 0, 0, 0);
+            if (n + kDepth < 288) px[n % kDepth] = read(n + kDepth);
+            __builtin_amdgcn_sched_barrier(0);
+            if ((n & 15) == 3) {  // 18 slots: eight DMA pieces, then the eight stores of the previous step
+                const int k = n >> 4;
+                if (k < 8)
+                    dma16(nxt_off[k], srd_in, 0, (unsigned)__builtin_amdgcn_readfirstlane((int)nxt_dst[k]));
+                else if (k < 16)
+                    store_piece(k - 8);
+            }
+        }
+
+        if (s == 0) stamp(p.stamps, 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned d[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4] = {fmaf(acc[i][4 * j], sc[j].x, sh[j].x), fmaf(acc[i][4 * j + 1], sc[j].y, sh[j].y),
+                              fmaf(acc[i][4 * j + 2], sc[j].z, sh[j].z), fmaf(acc[i][4 * j + 3], sc[j].w, sh[j].w)};
+                typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    bf16x2 o;
+                    o[0] = (bf16_t)(p.relu ? fmaxf(v[2 * c], 0.f) : v[2 * c]);
+                    o[1] = (bf16_t)(p.relu ? fmaxf(v[2 * c + 1], 0.f) : v[2 * c + 1]);
+                    d[j][c] = __builtin_bit_cast(unsigned, o);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const auto x0 = __builtin_amdgcn_permlane32_swap(d[2 * h][0], d[2 * h + 1][0], false, false);
+                const auto x1 = __builtin_amdgcn_permlane32_swap(d[2 * h][1], d[2 * h + 1][1], false, false);
+                pend[i][h] = i32x4{(int)x0[0], (int)x1[0], (int)x0[1], (int)x1[1]};
+            }
+            const int g = pixel_of(ub + 128 * s + 32 * i + li);
+            pend_off[i] = g < 0 ? kOob : g * 256 + (32 * wave + 8 * lh) * 2;
+        }
+        relbase = relbase + 128 >= kRing2 ? relbase + 128 - kRing2 : relbase + 128;
+        if (s == 0) stamp(p.stamps, 4);
+    }
+    stamp(p.stamps, 10);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) store_piece(q);
+}
+
 }  // namespace
 
 int rn_conv_wide_count(void) { return kNumTiles; }
@@ -725,10 +916,12 @@ void rn_conv_wide_launch(rn_ctx *ctx, GemmParams &p, int which, bool dual)
 
 bool rn_conv_strip_eligible(const GemmParams &p)
 {
-    return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.Cs == 64 && p.Cout == 64 &&
-           p.cseg == 1 && p.chunk_dw == 0 && p.kreal == 0 && p.tap_rows == 1 && p.residual == nullptr &&
-           p.Ho == p.H && p.Wo == p.W && p.W + 3 <= kStripMargin && p.Ktot == 576 &&
-           (uint64_t)(p.M / (p.H * p.W) * (p.H + 1) + 1) * (uint64_t)(p.W + 2) < (1ull << 30);
+    const bool common = p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.chunk_dw == 0 && p.kreal == 0 &&
+                        p.tap_rows == 1 && p.residual == nullptr && p.Ho == p.H && p.Wo == p.W &&
+                        (uint64_t)(p.M / (p.H * p.W) * (p.H + 1) + 1) * (uint64_t)(p.W + 2) < (1ull << 30);
+    if (!common) return false;
+    if (p.Cs == 64 && p.Cout == 64 && p.cseg == 1 && p.Ktot == 576) return p.W + 3 <= kStripMargin;
+    return p.Cs == 128 && p.Cout == 128 && p.cseg == 2 && p.Ktot == 1152 && p.W + 3 <= kMargin2;
 }
 
 void rn_conv_strip_launch(rn_ctx *ctx, const GemmParams &g)
@@ -740,9 +933,14 @@ void rn_conv_strip_launch(rn_ctx *ctx, const GemmParams &g)
     rn_fast_div((unsigned)p.Wp, &p.mul_wp, &p.shr_wp);
     rn_fast_div((unsigned)p.Hq, &p.mul_hq, &p.shr_hq);
     p.U = (p.B * p.Hq + 1) * p.Wp;
-    p.nsteps = (p.U + 255) / 256;
     p.in_bytes = g.in_bytes, p.out_bytes = g.out_bytes;
     p.stamps = g.stamps;
+    if (g.Cs == 128) {
+        p.nsteps = (p.U + 127) / 128;
+        conv_strip128_kernel<<<dim3(p.nsteps < 256 ? p.nsteps : 256), dim3(256), 0, ctx->stream>>>(p);
+        return;
+    }
+    p.nsteps = (p.U + 255) / 256;
     const int blocks = p.nsteps < 256 ? p.nsteps : 256;  // one block per CU
     conv_strip_kernel<<<dim3(blocks), dim3(512), 0, ctx->stream>>>(p);
 }

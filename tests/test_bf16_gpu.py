@@ -151,21 +151,24 @@ def test_wide_kernel_race_screen_at_full_size():
             lib.rn_ctx_set_conv_tile(ctx.handle, 0)
 
 
-STRIP_CASES = [(3, 20, 20), (1, 6, 6), (2, 56, 56), (5, 7, 61), (4, 1, 9), (2, 33, 5), (37, 28, 28)]
+STRIP_CASES = [(3, 20, 20, 64), (1, 6, 6, 64), (2, 56, 56, 64), (5, 7, 61, 64), (4, 1, 9, 64), (2, 33, 5, 64),
+               (37, 28, 28, 64), (3, 12, 12, 128), (1, 6, 6, 128), (2, 28, 28, 128), (5, 7, 29, 128), (4, 1, 9, 128),
+               (41, 14, 14, 128)]
 
 
 @pytest.mark.parametrize("case", STRIP_CASES)
 def test_strip_kernel_matches_oracle_and_the_tile_kernels_bits(case):
-    """conv_strip_kernel (3x3 / stride 1 / 64 -> 64 channels: weights in registers, the zero-padded
-    image in a rolling LDS ring, operands swapped, stores straight from registers) -- the candidate
-    after the wide tiles.  Against the oracle on bf16-rounded operands and bit for bit against a
-    4-wave tile: widest image the ring margin allows (61), one-row and narrow images, several
-    images per step and several steps per block (37 x 28 x 28: 479 steps on 256 blocks)."""
+    """conv_strip_kernel / conv_strip128_kernel (3x3 / stride 1 / 64 -> 64 and 128 -> 128 channels:
+    weights in registers, the zero-padded image in a rolling LDS ring, operands swapped, stores straight
+    from registers) -- the candidate after the wide tiles.  Against the oracle on bf16-rounded operands
+    and bit for bit against a 4-wave tile: widest image the ring margin allows (61 / 29), one-row and
+    narrow images, several images per step and several steps per block (37 x 28 x 28 x 64: 479 steps
+    on 256 blocks; 41 x 14 x 14 x 128: 308 steps)."""
     from resnet_c_amd import _lib as L
-    B, H, W = case
-    x, w = rnd((B, 64, H, W), 900 + sum(case)), rnd((64, 64, 3, 3), 901 + sum(case)) / 24.0
+    B, H, W, C = case
+    x, w = rnd((B, C, H, W), 900 + sum(case)), rnd((C, C, 3, 3), 901 + sum(case)) / np.sqrt(9.0 * C)
     g = np.random.default_rng(902 + sum(case))
-    sc, sh = g.random(64, dtype=np.float32) + 0.5, g.standard_normal(64, dtype=np.float32)
+    sc, sh = g.random(C, dtype=np.float32) + 0.5, g.standard_normal(C, dtype=np.float32)
     ctx, lib = R.get_ctx(), L.lib()
     strip = lib.rn_conv_tile_candidates()
     try:
