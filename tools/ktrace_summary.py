@@ -18,7 +18,7 @@ def family(name):
         return "conv_wide_kernel"
     if "stem_pool_kernel" in name:
         return "stem_pool_kernel"
-    if "conv_strip_kernel" in name:
+    if "conv_strip_kernel" in name or "conv_strip128_kernel" in name:
         return "conv_strip_kernel"
     if "chain_kernel" in name or "chain32_" in name:
         return "chain_kernel"

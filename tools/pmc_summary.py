@@ -26,6 +26,8 @@ def main():
                     short = fam + name.split(fam)[1].split(">")[0] + ">"
             if "conv_strip_kernel" in name:
                 short = "conv_strip_kernel"
+            if "conv_strip128_kernel" in name:
+                short = "conv_strip128_kernel"
             for fam in ("chain_kernel", "chain32_kernel", "chain32_pair_kernel"):
                 if fam in name:
                     short = fam + name.split(fam)[1].split("(")[0]

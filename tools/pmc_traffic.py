@@ -14,7 +14,7 @@ import os
 import sys
 
 
-FAMILY = ("conv_gemm_kernel", "conv_wide_kernel", "conv_strip_kernel", "chain_kernel", "chain32_", "splitk_finish_kernel",
+FAMILY = ("conv_gemm_kernel", "conv_wide_kernel", "conv_strip_kernel", "conv_strip128_kernel", "chain_kernel", "chain32_", "splitk_finish_kernel",
           "stem_pool_kernel")
 
 
