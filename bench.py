@@ -17,7 +17,9 @@ The JSON line also carries
                 FLOPs of its launches in one forward / their summed HIP-event durations,
                 measured on the library's stream in per-op instrumented forwards run
                 right after the timed region (the timed region itself is uninstrumented);
-  hbm_kernels   the same for the bandwidth-bound kernels (GB/s against 8 TB/s);
+  hbm_kernels   the same for the bandwidth-bound kernels (GB/s against 8 TB/s): those of the timed
+                (fused) forward plus, from a short leg in the one-kernel-per-reference-op mode run
+                after the timed region, batch-norm / ReLU / add / max-pool;
   cpu_baseline  oracle/torch_port.py (a torch.nn.functional port of the reference's
                 pytorch_inference.py, pinned by the golden logits) timed on this host's
                 CPU cores on a bounded sample, rank 0 at N=1 only.
@@ -97,7 +99,7 @@ def max_over_ranks(value: float, world: int, device=None) -> float:
     return float(t.item())
 
 
-def cpu_baseline(arch: str, state, seconds_budget: float = 15.0, engine=None):
+def cpu_baseline(arch: str, state, seconds_budget: float = 30.0, engine=None, batch: int = 256):
     """Reference-equivalent PyTorch forward on the host CPU, bounded sample.  `engine`: a callable
     (NCHW fp32 array -> logits) of the GPU path; the port's logits on the sample's first images
     are held against it in this very run (the port itself is pinned to the reference module's
@@ -113,17 +115,20 @@ def cpu_baseline(arch: str, state, seconds_budget: float = 15.0, engine=None):
     # makes oneDNN slower, not faster (measured: 30 img/s at 16 threads, 10 img/s at 128)
     threads = max(1, min(16, os.cpu_count() or 1))
     torch.set_num_threads(threads)
-    B = 32
+    # the bench batch itself (1 warm-up + 3 timed forwards of B = 256: about 35 s at
+    # ~30 images/s); the deeper networks run a smaller batch to stay inside the same budget
+    B = batch if arch == "resnet50" else max(32, batch // 4)
     x = torch.from_numpy(R.weights.generate_input(B, seed=123))
-    TP.resnet_forward(t, x[:2], arch)  # warm-up (thread pool, oneDNN primitives)
-    t0 = time.perf_counter()
-    y = TP.resnet_forward(t, x, arch)
-    one = time.perf_counter() - t0
-    reps = int(max(2, min(20, seconds_budget / max(one, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        y = TP.resnet_forward(t, x, arch)
-    dt = time.perf_counter() - t0
+    with torch.no_grad():
+        TP.resnet_forward(t, x[:2], arch)  # thread pool, oneDNN primitives
+        t0 = time.perf_counter()
+        y = TP.resnet_forward(t, x, arch)  # the warm-up forward at full size, also the time estimate
+        one = time.perf_counter() - t0
+        reps = int(max(1, min(3, seconds_budget / max(one, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = TP.resnet_forward(t, x, arch)
+        dt = time.perf_counter() - t0
     assert np.isfinite(y.numpy()).all()
     check = None
     if engine is not None:
@@ -131,29 +136,43 @@ def cpu_baseline(arch: str, state, seconds_budget: float = 15.0, engine=None):
         check = float(np.abs(got - y[:4].numpy()).max())
     return {"value": round(B * reps / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
             "max_abs_diff_vs_gpu_logits_on_4_images": check,
-            "sample": f"{reps} forwards of batch {B} ({arch} fp32, torch {torch.__version__} "
+            "sample": f"1 warm-up + {reps} timed forwards of batch {B} ({arch} fp32, torch {torch.__version__} "
                       f"functional port of pytorch_inference.py, {threads} threads of "
                       f"{os.cpu_count()} host cpus)"}
 
 
-def pmc_traffic(args):
-    """(HBM bytes per launch of the contraction kernels, file they come from).  Hardware counters
-    cannot be read from inside this process: the figure is the one of the committed rocprofv3
-    --pmc passes of this same command (profiles/round*/final_hbm_traffic_pmc*.json, made by
-    tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950),
-    NOT a measurement of this run; configurations without such a file report null."""
-    if not (args.arch == "resnet50" and args.batch == 256 and args.mode == "fused"):
-        return None, None
+def pmc_traffic(args, launches_per_forward: int):
+    """(HBM bytes per launch of the contraction kernels, file they come from, stale?).  Hardware
+    counters cannot be read from inside this process: the figure is the one of the committed
+    rocprofv3 --pmc passes of this same command (profiles/round*/final_hbm_traffic_pmc*.json, made
+    by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950).
+    That file carries the digest of the kernel sources it was measured on and its launch count:
+    when either differs from this build / this run the figure no longer describes what ran, and
+    the line says traffic = null, traffic_stale = true.  Configurations without a file: null."""
+    if not (args.batch == 256 and args.mode == "fused" and args.arch == "resnet50") and \
+            not (args.arch == "resnet152" and args.batch == 128 and args.mode == "fused" and args.dtype == "f32"):
+        return None, None, False
     import glob
 
-    name = "final_hbm_traffic_pmc.json" if args.dtype == "f32" else f"final_hbm_traffic_pmc_{args.dtype}.json"
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", name)))
+    import resnet_c_amd as R
+
+    tag = "" if args.dtype == "f32" else f"_{args.dtype}"
+    if args.arch != "resnet50":
+        tag += f"_{args.arch}_b{args.batch}"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"final_hbm_traffic_pmc{tag}.json")))
     if not files:
-        return None, None
+        return None, None, False
+    src = os.path.relpath(files[-1], ROOT)
     try:
-        return round(json.load(open(files[-1]))["traffic_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+        rec = json.load(open(files[-1]))
+        # the launch count moves by a few with the tuner's tile picks (a cut tail adds a finishing
+        # launch): more than that is another graph
+        if rec.get("source_digest") != R._lib.source_digest() or \
+                abs(int(rec.get("launches", -100)) - int(launches_per_forward)) > 4:
+            return None, src, True
+        return round(rec["traffic_bytes_per_launch"]), src, False
     except Exception:
-        return None, None
+        return None, src, True
 
 
 def summarize_profile(recs, n_forwards: int):
@@ -218,8 +237,12 @@ def main():
     ap.add_argument("--no-tune", action="store_true", help="skip the per-layer tile tuning pass")
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2, 4],
                     help="parts of a batch that run on streams of their own (they fill each other's kernel "
-                         "tails); 0 = the library's default: 1 for fp32 (+0.5 %% is not worth blurring the "
-                         "per-kernel times), 2 for bf16 storage (+9 %%)")
+                         "tails); 0 = the library's default (2 for fp32 and for bf16 storage); the roofline "
+                         "block and ms_per_step_one_stream are always taken on one stream")
+    ap.add_argument("--no-ops-leg", action="store_true",
+                    help="skip the short one-kernel-per-reference-op leg behind the timed region (fp32 fused "
+                         "runs take the batch-norm / ReLU / add / max-pool GB/s of hbm_kernels from it); "
+                         "profiler passes that pick 'the last forwards' of the process use this")
     ap.add_argument("--front-parts", type=int, default=1,
                     help="stem + max-pool + first stage in this many slices per batch part (Infinity-Cache reuse)")
     ap.add_argument("--profile-forwards", type=int, default=3)
@@ -294,6 +317,21 @@ def main():
     out = logits.numpy()
     assert np.isfinite(out).all(), "non-finite logits"
 
+    # the same steps with the whole batch on ONE stream (what the roofline block below describes)
+    ms_one_stream = elapsed / args.steps * 1e3
+    if args.streams > 1:
+        model.set_streams(1)
+        for _ in range(2):
+            model.forward_ptr(x_dev.data(), B, logits.data(), fused)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            model.forward_ptr(x_dev.data(), B, logits.data(), fused)
+        ctx.sync()
+        ms_one_stream = (time.perf_counter() - t1) / args.steps * 1e3
+        model.set_streams(args.streams)
+        assert np.array_equal(logits.numpy(), out), "one stream and several must give the same bits"
+
     # per-kernel durations: HIP events on the library's stream around every op
     model.set_profiling(True)
     recs = []
@@ -303,8 +341,19 @@ def main():
         model.forward_ptr(x_dev.data(), B, logits.data(), fused)
         recs += model.profile()
     kernel_launches = (lib.rn_ctx_launch_count(ctx.handle) - launches0) // max(1, args.profile_forwards)
-    model.set_profiling(False)
     fam = summarize_profile(recs, max(1, args.profile_forwards))
+    # north_star asks for the achieved HBM GB/s of batch-norm / ReLU / add / max-pool: the timed
+    # forward is fused and has none of them as kernels, so a short leg in the one-kernel-per-
+    # reference-op mode (same weights, same batch, same process) measures them
+    ops_fam = {}
+    if fused and args.dtype == "f32" and not args.no_ops_leg:
+        model.forward_ptr(x_dev.data(), B, logits.data(), False)  # untimed: first touch of its buffers
+        orecs = []
+        for _ in range(max(1, args.profile_forwards)):
+            model.forward_ptr(x_dev.data(), B, logits.data(), False)
+            orecs += model.profile()
+        ops_fam = summarize_profile(orecs, max(1, args.profile_forwards))
+    model.set_profiling(False)
 
     if rank != 0:
         return
@@ -327,6 +376,13 @@ def main():
         gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
         hbm[k] = {"launches": f["launches"], "ms_per_forward": round(f["ms"], 4),
                   "GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)}
+    for k in ("batchnorm2d", "relu", "add", "maxpool2d"):
+        f = ops_fam.get(k)
+        if f and f["ms"] > 0 and k not in hbm:
+            gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
+            hbm[k] = {"launches": f["launches"], "ms_per_forward": round(f["ms"], 4), "GBps": round(gbs, 1),
+                      "frac": round(gbs / PEAK_HBM_GBS, 4),
+                      "from": "ops-mode leg (one kernel per reference op) behind the timed region"}
     peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
     prec = "fp32" if args.dtype == "f32" else "bf16"
     g_gbps = g_bytes / (g_ms * 1e-3) / 1e9 if g_ms > 0 else 0.0
@@ -334,7 +390,7 @@ def main():
     # (fp32: the matrix pipe; bf16 storage: 16x the matrix rate on half the bytes -> HBM)
     frac_mfma, frac_hbm = achieved / peak, g_gbps / PEAK_HBM_GBS
     bound = "mfma" if frac_mfma >= frac_hbm else "hbm"
-    traffic, traffic_source = pmc_traffic(args)
+    traffic, traffic_source, traffic_stale = pmc_traffic(args, g_launch)
     result = {
         "metric": "images/sec ResNet-50 224x224 fp32 batch=256"
                   if args.arch == "resnet50" and B == 256 and args.dtype == "f32"
@@ -345,6 +401,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_step_one_stream": round(ms_one_stream, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -364,7 +421,8 @@ def main():
                      "peak": peak if bound == "mfma" else PEAK_HBM_GBS,
                      "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                      "frac": round(max(frac_mfma, frac_hbm), 4),
-                     "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
+                     "source_digest": R._lib.source_digest(),
                      "kernel": "conv_gemm_kernel" + (" / conv_wide_kernel / conv_strip_kernel / chain_kernel" if args.dtype == "bf16" else " / chain32_kernel") +
                                " (implicit-GEMM conv2d + fc on " +
                                ("v_mfma_f32_32x32x2_f32)" if args.dtype == "f32" else "v_mfma_f32_32x32x16_bf16)"),
@@ -385,7 +443,7 @@ def main():
     if world == 1 and not args.no_pipeline:
         result["host_pipeline"] = host_pipeline(model, x_host, B, fused, args.steps)
     if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(args.arch, state,
+        result["cpu_baseline"] = cpu_baseline(args.arch, state, batch=B,
                                               engine=lambda a: model.forward(a, fused=fused))
         diff = result["cpu_baseline"]["max_abs_diff_vs_gpu_logits_on_4_images"]
         assert diff is not None and diff <= (1e-4 if args.dtype == "f32" else 0.25), diff

@@ -256,7 +256,20 @@ RN_API int rn_model_set_dtype(rn_model *m, int dtype);
 RN_API int rn_model_finalize(rn_model *m);
 /* names of the tensors the loader expects, one per call; returns NULL past the end */
 RN_API const char *rn_model_tensor_key(const rn_model *m, uint64_t index, uint64_t *numel);
-/* input: device NCHW [B,3,224,224]; logits: device [B,1000]. Asynchronous on the stream. */
+/* input: device NCHW [B,3,224,224]; logits: device [B,1000]. Asynchronous on the stream.
+ *
+ * Fixed geometry of the model driver (the op entry points above are general; the driver, like
+ * the reference's -- main.cu:230 hard-codes {1, 3, 224, 224} -- is not):
+ *   - images are 3 x 224 x 224 fp32, NCHW; there is no size argument, so a buffer of another
+ *     geometry cannot be expressed: callers that read files check the element count first
+ *     (rn_infer does and reports RN_ERR_UNSUPPORTED's text for anything but B*3*224*224 floats);
+ *   - 1000 classes, bottleneck depths 50 / 101 / 152;
+ *   - any B >= 1: the kernels address a tensor with 32-bit byte offsets (2^29 fp32 elements; the
+ *     stem output of 669 images is the first to pass it), so a batch runs as sub-batches of at
+ *     most 512 images through the same arenas, each as `streams` parts (rn_model_set_streams);
+ *     every image's logits are independent of that split, bit for bit;
+ *   - arenas: 13.6 MB (fp32) / 6.8 MB (bf16) of activations per image of the largest sub-batch
+ *     seen, allocated on first use (RN_ERR_NOMEM when the device cannot hold them). */
 RN_API int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *logits,
                             int mode);
 /* Run one forward, then time every tile candidate of every convolution at batch B on the
@@ -275,8 +288,9 @@ RN_API int rn_model_set_stem_exact(rn_model *m, int on);
  * each) on streams of their own -- the launches of one part fill the tails of the others';
  * every image's logits are independent of what else is in its launch, so no bit changes.
  * Default: 2 (measured at B = 256: fp32 +0.8 %, bf16 storage +5..9 %: its 256-wide tiles leave
- * CUs idle in the late stages).  Profiled and tuning forwards always use one stream.  Changing it invalidates the
- * tuned tiles. */
+ * CUs idle in the late stages).  Profiled and tuning forwards always use one stream.  Tuned tiles
+ * are kept per launch batch size (rn_model_tune times the parts' size and the whole batch), so
+ * switching between the tuned part count and one stream keeps them. */
 RN_API int rn_model_set_streams(rn_model *m, int streams);
 RN_API int rn_model_get_streams(const rn_model *m);
 /* parts = 1 (default), 2, 4, 8 or 16: the stem, the max-pool and the first stage -- the layers
@@ -316,7 +330,9 @@ RN_API int rn_conv2d_nhwc_exact_forward(rn_ctx *ctx, const float *inp_padded, fl
  * own 3-pixel zero border (rn_nchw_to_nhwc_pad_dt with border 3; Cpad = 3 for fp32, 4 for
  * bf16), [B,Hp,Wp,Cpad]; out: [B,PH,PW,64] of `dtype`.  Needs 64 output channels, a conv
  * output width that is a multiple of 8 and at most 128 (ResNet: 112).  scale/shift: per
- * channel, nullable.  Same products as conv + bn + relu + maxpool, summed in another order. */
+ * channel, nullable.  Same products as conv + bn + relu + maxpool, summed in another order.
+ * relu must be non-zero (RN_ERR_INVALID otherwise): the pool is taken as an integer maximum of
+ * the non-negative ReLU outputs' bit patterns. */
 RN_API uint64_t rn_stem_pool_packed_weight_numel(int dtype);
 RN_API int rn_stem_pool_pack_weight_dt(rn_ctx *ctx, int dtype, const float *weight_oihw /* [64,Cin,7,7] */,
                                        void *packed, uint64_t in_channels);
@@ -421,6 +437,11 @@ RN_API int rn_pipeline_submit(rn_pipeline *p, const float *host_input_nchw);
 /* host_logits: B*1000 floats.  RN_ERR_INVALID when nothing is in flight. */
 RN_API int rn_pipeline_collect(rn_pipeline *p, float *host_logits);
 RN_API uint64_t rn_pipeline_in_flight(const rn_pipeline *p);
+/* The same for a batch of n <= B images (a ragged last batch), and with the class indices
+ * (first maximum wins, main.cu:243-249) next to the logits; host_logits ([n,1000]), host_top1
+ * ([n]) and n may each be NULL. */
+RN_API int rn_pipeline_submit_n(rn_pipeline *p, const float *host_input_nchw, uint64_t n);
+RN_API int rn_pipeline_collect_n(rn_pipeline *p, float *host_logits, uint64_t *host_top1, uint64_t *n);
 
 /* ---- one batch over several devices of a node ---------------------------------------
  * The multi-device form of the reference's main() (main.cu:228-254).  The forward has no
@@ -444,6 +465,25 @@ RN_API int rn_shard_forward(rn_shard *g, const float *host_input_nchw, uint64_t 
                             float *host_logits, uint64_t *host_top1, int mode);
 /* rn_model_tune on every shard, at the batch size each shard sees for a batch of B */
 RN_API int rn_shard_tune(rn_shard *g, const float *host_input_nchw, uint64_t B, int mode);
+/* Upload, forward and download overlap on every device (main.cu:236-240 and tensor.cuh:184-199
+ * do them strictly in sequence, from pageable memory): each device owns an rn_pipeline -- pinned
+ * staging, a copy stream, two slots.  rn_shard_forward sends a shard through it in chunks of at
+ * most 256 images, two in flight.  The streaming form below keeps two whole BATCHES in flight:
+ *   rn_shard_stream_open(g, B, mode);            shard r owns images rn_shard_bounds(B, r, G)
+ *   rn_shard_submit(g, batch0); rn_shard_submit(g, batch1);
+ *   rn_shard_collect(g, logits0, top1_0); rn_shard_submit(g, batch2); ...
+ * submit returns once every device has queued its shard (the copy into pinned staging is done
+ * by the device's own host thread, all devices in parallel); collect returns the oldest batch,
+ * rows in image order.  rn_shard_stream_buffer gives shard `rank`'s pinned staging buffer of the
+ * NEXT submit and the image range [lo, hi) it holds: a decoder that writes there and submits
+ * NULL saves the host-side copy.  At most two batches in flight (RN_ERR_INVALID otherwise). */
+RN_API int rn_shard_stream_open(rn_shard *g, uint64_t B, int mode);
+RN_API int rn_shard_stream_buffer(rn_shard *g, int rank, float **host_staging, uint64_t *lo,
+                                  uint64_t *hi);
+RN_API int rn_shard_submit(rn_shard *g, const float *host_input_nchw /* NULL: staging filled */);
+RN_API int rn_shard_collect(rn_shard *g, float *host_logits, uint64_t *host_top1);
+RN_API int rn_shard_in_flight(const rn_shard *g);
+RN_API int rn_shard_stream_close(rn_shard *g);
 
 #ifdef __cplusplus
 }

@@ -137,6 +137,8 @@ SIGNATURES = {
     "rn_pipeline_submit": (c_int, [c_void_p, c_void_p]),
     "rn_pipeline_collect": (c_int, [c_void_p, c_void_p]),
     "rn_pipeline_in_flight": (u64, [c_void_p]),
+    "rn_pipeline_submit_n": (c_int, [c_void_p, c_void_p, u64]),
+    "rn_pipeline_collect_n": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(u64)]),
     "rn_shard_bounds": (None, [u64, c_int, c_int, POINTER(u64), POINTER(u64)]),
     "rn_shard_create": (c_int, [POINTER(c_void_p), POINTER(c_int), c_int, c_int]),
     "rn_shard_destroy": (c_int, [c_void_p]),
@@ -148,6 +150,12 @@ SIGNATURES = {
     "rn_shard_finalize": (c_int, [c_void_p]),
     "rn_shard_forward": (c_int, [c_void_p, c_void_p, u64, c_void_p, c_void_p, c_int]),
     "rn_shard_tune": (c_int, [c_void_p, c_void_p, u64, c_int]),
+    "rn_shard_stream_open": (c_int, [c_void_p, u64, c_int]),
+    "rn_shard_stream_buffer": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(u64), POINTER(u64)]),
+    "rn_shard_submit": (c_int, [c_void_p, c_void_p]),
+    "rn_shard_collect": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "rn_shard_in_flight": (c_int, [c_void_p]),
+    "rn_shard_stream_close": (c_int, [c_void_p]),
 }
 
 _lib = None
@@ -182,6 +190,25 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def source_digest() -> str:
+    """sha256 (16 hex digits) over the sources librn_hip.so is built from: what a measurement of
+    the kernels (a PMC pass, a trace) is stamped with, so that a later build can tell whether
+    the figure still describes it.  (The GPU box has no .git; a commit id would also change with
+    every documentation commit.)"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.c")) + glob.glob(os.path.join(_HERE, "csrc", "Makefile")) +
+                   [os.path.join(os.path.dirname(_HERE), "include", "rn_hip.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def check(status: int, where: str, ctx=None) -> None:

@@ -641,6 +641,16 @@ int chain_launch(rn_ctx *ctx, const char *what, int dtype, const void *t2, const
     if (rows == 0) return RN_OK;
     RN_REQUIRE(ctx, dtype == RN_DTYPE_BF16 || dtype == RN_DTYPE_F32, "unknown dtype");
     RN_REQUIRE(ctx, t2 && x && y && w3 && t1 && w1, "null tensor");
+    // the kernels move 16-byte pieces (LDS-DMA, b128 buffer loads and stores, float4 loads of the
+    // folded batch-norm constants): a misaligned pointer would fault or silently shift data
+    RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(t2) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                      reinterpret_cast<uintptr_t>(t1) | reinterpret_cast<uintptr_t>(w3) | reinterpret_cast<uintptr_t>(w1) |
+                      reinterpret_cast<uintptr_t>(scale3) | reinterpret_cast<uintptr_t>(shift3) |
+                      reinterpret_cast<uintptr_t>(scale1) | reinterpret_cast<uintptr_t>(shift1)) & 15) == 0,
+               "tensors, panels and scale / shift vectors must be 16-byte aligned");
+    // a block reads t2 / x rows one step ahead of the rows it writes: an output on top of an input
+    // (or y on top of t1) is read back half-written
+    RN_REQUIRE(ctx, y != t1 && y != t2 && y != x && t1 != t2 && t1 != x, "y and t1 must not alias each other or an input");
     const bool s1 = mid_channels == 64 && channels == 256 && (next_mid == 64 || next_mid == 128);
     const bool s2 = mid_channels == 128 && channels == 512 && next_mid == 128 && !dual && dtype == RN_DTYPE_BF16;
     RN_REQUIRE(ctx, s1 || s2, "shapes: 64 -> 256 -> 64 | 128 channels, or (bf16) 128 -> 512 -> 128");

@@ -1285,7 +1285,12 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
             RN_TRY(rn_wcache_add(ctx, weight, in_channels, out_channels, kernel_size, wn * sizeof(float), &wp));
         else
             RN_TRY(rn_scratch(ctx, 1, wn * sizeof(float), &wp));
-        RN_TRY(rn_conv2d_pack_weight(ctx, weight, (float *)wp, in_channels, out_channels, kernel_size));
+        const int pst = rn_conv2d_pack_weight(ctx, weight, (float *)wp, in_channels, out_channels, kernel_size);
+        if (pst != RN_OK) {
+            // a cached entry whose panel was never filled must not answer the next lookup
+            if (ctx->wcache_on) rn_wcache_remove(ctx, wp);
+            return pst;
+        }
     }
     if (ctx->layout == RN_LAYOUT_NHWC) {
         return launch_gemm(ctx, RN_DTYPE_F32, RN_DTYPE_F32, inp, out, wp, kernel_size, stride,

@@ -87,13 +87,29 @@ int rn_wcache_add(rn_ctx *ctx, const void *weight, uint64_t cin, uint64_t cout, 
     return RN_OK;
 }
 
+void rn_wcache_remove(rn_ctx *ctx, const void *packed)
+{
+    for (int i = 0; i < ctx->wcache_n; ++i) {
+        if (ctx->wcache[i].packed != packed) continue;
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->wcache[i].packed);
+        ctx->wcache[i] = ctx->wcache[--ctx->wcache_n];
+        return;
+    }
+}
+
 void rn_wcache_drop(rn_ctx *ctx, const void *lo, uint64_t bytes)
 {
-    const uintptr_t a = (uintptr_t)lo, b = a + (bytes ? bytes : 1);
+    // a write that starts INSIDE a cached weight buffer stales its panel too: compare intervals,
+    // [key, key + extent) of the OIHW weight against [lo, lo + bytes) of the write
+    const uintptr_t a = (uintptr_t)lo;
+    const uintptr_t b = bytes >= ~(uintptr_t)0 - a ? ~(uintptr_t)0 : a + (bytes ? bytes : 1);
     int kept = 0, dropped = 0;
     for (int i = 0; i < ctx->wcache_n; ++i) {
-        const uintptr_t key = (uintptr_t)ctx->wcache[i].key;
-        if (key >= a && key < b) {
+        const rn_wcache_entry &e = ctx->wcache[i];
+        const uintptr_t key = (uintptr_t)e.key;
+        const uintptr_t end = key + (uintptr_t)(e.cin * e.cout * e.k * e.k * sizeof(float));
+        if (key < b && end > a) {
             if (!dropped++) (void)hipStreamSynchronize(ctx->stream);  // a queued launch may read it
             (void)hipFree(ctx->wcache[i].packed);
         } else {

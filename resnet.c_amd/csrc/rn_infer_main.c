@@ -54,8 +54,9 @@ static int run_sharded(const int *devices, int ndev, int arch, const char *weigh
     idx = (uint64_t *)malloc(B * sizeof(uint64_t));
     f = fopen(input, "rb");
     if (!host || !idx || !f || fread(host, sizeof(float), want, f) != want || fgetc(f) != EOF) {
-        fprintf(stderr, "rn_infer: %s does not hold exactly %llu floats (batch %llu)\n", input,
-                (unsigned long long)want, (unsigned long long)B);
+        fprintf(stderr, "rn_infer: %s: %s: the model driver takes 3 x 224 x 224 fp32 images only; the file "
+                        "does not hold exactly %llu floats (batch %llu)\n", rn_status_string(RN_ERR_UNSUPPORTED),
+                input, (unsigned long long)want, (unsigned long long)B);
         return 1;
     }
     fclose(f);
@@ -114,7 +115,8 @@ int main(int argc, char **argv)
 
     CHECK(ctx, rn_load_f32_file(ctx, input, &inp, &numel));
     if (numel != B * 3 * 224 * 224) {
-        fprintf(stderr, "rn_infer: %s holds %llu floats, expected %llu for batch %llu\n", input,
+        fprintf(stderr, "rn_infer: %s: the model driver takes 3 x 224 x 224 fp32 images only; %s holds "
+                        "%llu floats, expected %llu for batch %llu\n", rn_status_string(RN_ERR_UNSUPPORTED), input,
                 (unsigned long long)numel, (unsigned long long)(B * 3 * 224 * 224),
                 (unsigned long long)B);
         return 1;

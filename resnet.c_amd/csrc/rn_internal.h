@@ -52,10 +52,12 @@ int rn_check_hip(rn_ctx *ctx, hipError_t e, const char *what);
 // scratch slot `slot` with at least `bytes`; contents undefined
 int rn_scratch(rn_ctx *ctx, int slot, uint64_t bytes, void **ptr);
 // packed-weight cache: the panel for (weight, shape), or null; add = allocate an entry's panel
-// (the caller packs into it); drop = forget every entry whose key lies in [lo, lo + bytes)
+// (the caller packs into it; remove = take that entry back when the pack failed); drop = forget
+// every entry whose weight buffer [key, key + cin*cout*k*k*4) overlaps [lo, lo + bytes)
 void *rn_wcache_find(rn_ctx *ctx, const void *weight, uint64_t cin, uint64_t cout, uint64_t k);
 int rn_wcache_add(rn_ctx *ctx, const void *weight, uint64_t cin, uint64_t cout, uint64_t k,
                   uint64_t bytes, void **packed);
+void rn_wcache_remove(rn_ctx *ctx, const void *packed);
 void rn_wcache_drop(rn_ctx *ctx, const void *lo, uint64_t bytes);
 // launch epilogue shared by every op: launch-error check and optional per-op sync
 int rn_after_launch(rn_ctx *ctx, const char *what);

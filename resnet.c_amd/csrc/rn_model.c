@@ -45,8 +45,11 @@ typedef struct {
     int w, bn_w, bn_b, bn_m, bn_v; /* indices into params */
     void *packed;                  /* K-major panel, model dtype */
     float *scale, *shift;          /* folded batch-norm */
-    int tile;                      /* tuned contraction tile (0 = per-launch choice) */
-    uint64_t tile_B;               /* ... and the launch batch it was tuned at */
+    /* tuned contraction tile (0 = per-launch choice) and the launch batch it was tuned at: slot 0
+     * for the parts a batch runs as on its streams, slot 1 for the whole (sub-)batch on one stream
+     * (profiled forwards, rn_model_set_streams(m, 1)) */
+    int tile[2];
+    uint64_t tile_B[2];
 } rn_conv;
 
 typedef struct {
@@ -57,8 +60,8 @@ typedef struct {
      * folded in, and the sum of the two shifts */
     void *pair_packed;
     float *pair_shift;
-    int pair_tile;
-    uint64_t pair_tile_B;
+    int pair_tile[2];
+    uint64_t pair_tile_B[2];
 } rn_block;
 
 typedef struct {
@@ -376,12 +379,12 @@ int rn_model_set_dtype(rn_model *m, int dtype)
     for (c = 0; c < m->n_convs; ++c) {
         rn_free(m->ctx, m->convs[c].packed);
         m->convs[c].packed = NULL;
-        m->convs[c].tile = 0;
+        m->convs[c].tile[0] = m->convs[c].tile[1] = 0;
     }
     for (c = 0; c < m->n_blocks; ++c) {
         rn_free(m->ctx, m->blocks[c].pair_packed);
         m->blocks[c].pair_packed = NULL;
-        m->blocks[c].pair_tile = 0;
+        m->blocks[c].pair_tile[0] = m->blocks[c].pair_tile[1] = 0;
     }
     rn_free(m->ctx, m->fc_packed);
     m->fc_packed = NULL;
@@ -520,6 +523,20 @@ uint64_t rn_model_activation_bytes(const rn_model *m) { return m ? m->act_bytes 
 
 /* library-internal: the pipeline (rn_pipeline.hip) queues on the model's stream */
 rn_ctx *rn_model_context(rn_model *m) { return m ? m->ctx : NULL; }
+
+/* library-internal: every context the model has queued batch parts on (m->ctx and the m->ctxn[]
+ * of the other streams).  A captured forward holds pointers into the scratch of each of them:
+ * rn_model_capture pins them all for the graph's lifetime (rn_scratch refuses to grow a pinned
+ * context's slots). */
+int rn_model_contexts(rn_model *m, rn_ctx **out, int cap)
+{
+    int k, n = 0;
+    if (!m || !out) return 0;
+    if (n < cap) out[n++] = m->ctx;
+    for (k = 0; k < RN_MAX_STREAMS - 1; ++k)
+        if (m->ctxn[k] && n < cap) out[n++] = m->ctxn[k];
+    return n;
+}
 int rn_model_set_pair_fusion(rn_model *m, int on)
 {
     if (!m) return RN_ERR_INVALID;
@@ -533,7 +550,7 @@ int rn_model_set_streams(rn_model *m, int streams)
     if (!m || (streams != 1 && streams != 2 && streams != 4)) return RN_ERR_INVALID;
     m->streams = streams;
     m->streams_set = 1;
-    m->tuned_B = 0; /* the launches change size */
+    /* the tuned tiles are looked up by launch batch size: those of other part sizes simply stop matching */
     return RN_OK;
 }
 
@@ -660,6 +677,13 @@ static rn_conv_call *next_call(rn_model *m)
     return &m->calls[m->n_calls++];
 }
 
+/* the tile tuned for a launch of B images in the current mode, or 0 = per-launch choice */
+static int tuned_tile(const rn_model *m, const int tile[2], const uint64_t tile_B[2], uint64_t B)
+{
+    if (!m->tuned_B || m->tuned_mode != m->cur_mode) return 0;
+    return tile_B[0] == B ? tile[0] : tile_B[1] == B ? tile[1] : 0;
+}
+
 #define RN_PAD_EXACT (-2)
 static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint64_t B, uint64_t H,
                    uint64_t W, const rn_epilogue *ep, int64_t pad_override)
@@ -690,7 +714,7 @@ static int op_conv(rn_model *m, const rn_conv *cv, const void *x, void *y, uint6
     }
     TRY(prof_begin(m, ep ? "conv2d+epilogue" : "conv2d", cv->name, 2.0 * M * (double)cv->cout * K,
                    bytes));
-    rn_ctx_set_conv_tile(m->run, (m->tuned_B && cv->tile_B == B && m->tuned_mode == m->cur_mode) ? cv->tile : 0);
+    rn_ctx_set_conv_tile(m->run, tuned_tile(m, cv->tile, cv->tile_B, B));
     {
         const int st =
             exact ? rn_conv2d_nhwc_exact_forward(m->run, (const float *)x, (float *)y,
@@ -733,7 +757,7 @@ static int op_pair(rn_model *m, rn_block *b, const void *t, const void *x, void 
     }
     snprintf(name, sizeof(name), "%.*s+downsample", (int)(RN_MAX_KEY - 12), c3->name);
     TRY(prof_begin(m, "conv2d+epilogue", name, 2.0 * M * (double)c3->cout * K, bytes));
-    rn_ctx_set_conv_tile(m->run, (m->tuned_B && b->pair_tile_B == B && m->tuned_mode == m->cur_mode) ? b->pair_tile : 0);
+    rn_ctx_set_conv_tile(m->run, tuned_tile(m, b->pair_tile, b->pair_tile_B, B));
     st = rn_conv2d_nhwc_pair_forward_dt(m->run, m->dtype, m->dtype, t, y, b->pair_packed, c3->k,
                                         c3->stride, c3->pad, H, W, B, c3->cin, c3->cout, H, W,
                                         &second, &ep);
@@ -1118,22 +1142,15 @@ int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *lo
     return RN_OK;
 }
 
-int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
+/* time every tile candidate of every contraction of a forward of B images (one launch batch);
+ * the winners go to slot `slot` of the layers' tile tables */
+static int tune_at(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode, int slot)
 {
     rn_event *e0 = NULL, *e1 = NULL;
     const int ncand = rn_conv_tile_candidates();
     int i, c, r, st;
-    const uint64_t B_all = B;
-    if (!m) return RN_ERR_INVALID;
-    if (B > RN_MAX_SUB_BATCH) B = RN_MAX_SUB_BATCH; /* the launches of a larger batch are sub-batches */
-    {   /* ... and those run as `streams` parts */
-        int parts = m->streams;
-        while (parts > 1 && B / (uint64_t)parts < RN_STREAM_MIN_PART) parts /= 2;
-        if (parts > 1) B /= (uint64_t)parts;
-    }
     m->single_stream_only = 1;
     /* one recorded forward with the per-launch choice: fills the buffers with real data */
-    m->tuned_B = 0;
     m->n_calls = 0;
     m->recording = 1;
     st = rn_model_forward(m, input_nchw, B, logits, mode);
@@ -1188,16 +1205,38 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
             }
         }
         if (k->pair_block >= 0) {
-            m->blocks[k->pair_block].pair_tile = best_c;
-            m->blocks[k->pair_block].pair_tile_B = k->B;
+            m->blocks[k->pair_block].pair_tile[slot] = best_c;
+            m->blocks[k->pair_block].pair_tile_B[slot] = k->B;
         } else {
-            cv->tile = best_c;
-            cv->tile_B = k->B;
+            cv->tile[slot] = best_c;
+            cv->tile_B[slot] = k->B;
         }
     }
     rn_ctx_set_conv_tile(m->ctx, 0);
     rn_event_destroy(e0);
     rn_event_destroy(e1);
+    return st;
+}
+
+int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
+{
+    const uint64_t B_all = B;
+    uint64_t Bp;
+    int c, st;
+    if (!m) return RN_ERR_INVALID;
+    if (B > RN_MAX_SUB_BATCH) B = RN_MAX_SUB_BATCH; /* the launches of a larger batch are sub-batches */
+    Bp = B;
+    {   /* ... and those run as `streams` parts */
+        int parts = m->streams;
+        while (parts > 1 && B / (uint64_t)parts < RN_STREAM_MIN_PART) parts /= 2;
+        if (parts > 1) Bp = B / (uint64_t)parts;
+    }
+    m->tuned_B = 0;
+    for (c = 0; c < m->n_convs; ++c) m->convs[c].tile_B[0] = m->convs[c].tile_B[1] = 0;
+    for (c = 0; c < m->n_blocks; ++c) m->blocks[c].pair_tile_B[0] = m->blocks[c].pair_tile_B[1] = 0;
+    st = tune_at(m, input_nchw, Bp, logits, mode, 0);
+    /* the whole (sub-)batch on one stream is what a profiled forward launches: its own tiles */
+    if (st == RN_OK && Bp != B) st = tune_at(m, input_nchw, B, logits, mode, 1);
     if (st != RN_OK) return st;
     m->tuned_B = B;
     m->tuned_mode = mode;

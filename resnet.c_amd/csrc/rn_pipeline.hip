@@ -9,6 +9,8 @@
 
 struct rn_graph {
     rn_ctx *ctx;
+    rn_ctx *pinned[8];  // every context the model queued batch parts on: pinned while the graph lives
+    int n_pinned;
     hipGraph_t graph;
     hipGraphExec_t exec;
     size_t nodes;
@@ -17,6 +19,8 @@ struct rn_graph {
 struct rn_pipeline_slot {
     float *h_in, *h_out;  // pinned
     float *d_in, *d_out;
+    uint64_t *h_idx, *d_idx;  // class indices (first maximum wins, main.cu:243-249)
+    uint64_t n;               // images of the batch in this slot (<= B)
     hipEvent_t uploaded, done;
     int busy;
 };
@@ -37,6 +41,8 @@ extern "C" {
 rn_ctx *rn_model_context(rn_model *m);
 
 int rn_model_profiling_enabled(const rn_model *m);
+// the contexts the model has queued batch parts on so far (rn_model.c)
+int rn_model_contexts(rn_model *m, rn_ctx **out, int cap);
 
 int rn_graph_destroy(rn_graph *g)
 {
@@ -44,7 +50,7 @@ int rn_graph_destroy(rn_graph *g)
     if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
     if (g->exec) {
         (void)hipGraphExecDestroy(g->exec);
-        if (g->ctx) --g->ctx->graphs_live;
+        for (int i = 0; i < g->n_pinned; ++i) --g->pinned[i]->graphs_live;
     }
     if (g->graph) (void)hipGraphDestroy(g->graph);
     free(g);
@@ -85,7 +91,10 @@ int rn_model_capture(rn_model *m, const float *input_nchw, uint64_t B, float *lo
         rn_graph_destroy(g);
         return rn_check_hip(ctx, e, "hipGraphInstantiate");
     }
-    ++ctx->graphs_live;  // from here on the scratch and the arenas must stay where they are
+    // from here on the scratch and the arenas must stay where they are: the captured nodes point
+    // into the scratch of the primary context AND of the contexts of the other batch parts
+    g->n_pinned = rn_model_contexts(m, g->pinned, 8);
+    for (int i = 0; i < g->n_pinned; ++i) ++g->pinned[i]->graphs_live;
     e = hipGraphGetNodes(g->graph, nullptr, &g->nodes);
     if (e != hipSuccess) {
         rn_graph_destroy(g);
@@ -108,14 +117,17 @@ uint64_t rn_graph_node_count(const rn_graph *g) { return g ? (uint64_t)g->nodes 
 int rn_pipeline_destroy(rn_pipeline *p)
 {
     if (!p) return RN_OK;
+    if (p->ctx) (void)hipSetDevice(p->ctx->device);
     if (p->ctx) (void)hipStreamSynchronize(p->ctx->stream);
     if (p->copy_stream) (void)hipStreamSynchronize(p->copy_stream);
     for (int i = 0; i < 2; ++i) {
         rn_pipeline_slot *s = &p->slot[i];
         if (s->h_in) (void)hipHostFree(s->h_in);
         if (s->h_out) (void)hipHostFree(s->h_out);
+        if (s->h_idx) (void)hipHostFree(s->h_idx);
         if (s->d_in) (void)hipFree(s->d_in);
         if (s->d_out) (void)hipFree(s->d_out);
+        if (s->d_idx) (void)hipFree(s->d_idx);
         if (s->uploaded) (void)hipEventDestroy(s->uploaded);
         if (s->done) (void)hipEventDestroy(s->done);
     }
@@ -137,14 +149,17 @@ int rn_pipeline_create(rn_model *m, rn_pipeline **out, uint64_t B, int mode)
     p->mode = mode;
     const size_t in_bytes = (size_t)B * 3 * 224 * 224 * sizeof(float);
     const size_t out_bytes = (size_t)B * 1000 * sizeof(float);
+    const size_t idx_bytes = (size_t)B * sizeof(uint64_t);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
         rn_pipeline_slot *s = &p->slot[i];
         e = hipHostMalloc((void **)&s->h_in, in_bytes, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out, out_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_idx, idx_bytes, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_in, in_bytes);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_out, out_bytes);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_idx, idx_bytes);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
     }
@@ -158,6 +173,7 @@ int rn_pipeline_create(rn_model *m, rn_pipeline **out, uint64_t B, int mode)
 }
 
 uint64_t rn_pipeline_in_flight(const rn_pipeline *p) { return p ? p->head - p->tail : 0; }
+uint64_t rn_pipeline_batch(const rn_pipeline *p) { return p ? p->B : 0; }
 
 int rn_pipeline_input_buffer(rn_pipeline *p, float **host_staging)
 {
@@ -168,16 +184,18 @@ int rn_pipeline_input_buffer(rn_pipeline *p, float **host_staging)
     return RN_OK;
 }
 
-int rn_pipeline_submit(rn_pipeline *p, const float *host_input_nchw)
+int rn_pipeline_submit_n(rn_pipeline *p, const float *host_input_nchw, uint64_t n)
 {
     if (!p) return RN_ERR_INVALID;
     rn_ctx *ctx = p->ctx;
     RN_TRY(rn_bind_device(ctx));
+    if (n == 0 || n > p->B)
+        return rn_set_error(ctx, RN_ERR_INVALID, "rn_pipeline_submit_n: %llu images, the pipeline holds 1..%llu",
+                            (unsigned long long)n, (unsigned long long)p->B);
     if (p->head - p->tail >= 2)
         return rn_set_error(ctx, RN_ERR_INVALID, "rn_pipeline_submit: both slots busy, collect first");
     rn_pipeline_slot *s = &p->slot[p->head & 1];
-    const size_t in_bytes = (size_t)p->B * 3 * 224 * 224 * sizeof(float);
-    const size_t out_bytes = (size_t)p->B * 1000 * sizeof(float);
+    const size_t in_bytes = (size_t)n * 3 * 224 * 224 * sizeof(float);
     if (host_input_nchw && host_input_nchw != s->h_in)
         memcpy(s->h_in, host_input_nchw, in_bytes);  // pageable -> pinned
     RN_HIP_TRY(ctx, hipMemcpyAsync(s->d_in, s->h_in, in_bytes, hipMemcpyHostToDevice, p->copy_stream));
@@ -185,26 +203,45 @@ int rn_pipeline_submit(rn_pipeline *p, const float *host_input_nchw)
     // forward on the compute stream once the upload has landed; the other slot's forward may
     // still be running there, which is exactly the overlap
     RN_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->uploaded, 0));
-    RN_TRY(rn_model_forward(p->model, s->d_in, p->B, s->d_out, p->mode));
-    RN_HIP_TRY(ctx, hipMemcpyAsync(s->h_out, s->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RN_TRY(rn_model_forward(p->model, s->d_in, n, s->d_out, p->mode));
+    RN_TRY(rn_argmax_forward(ctx, s->d_out, s->d_idx, n, 1000));
+    RN_HIP_TRY(ctx, hipMemcpyAsync(s->h_out, s->d_out, (size_t)n * 1000 * sizeof(float), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    RN_HIP_TRY(ctx, hipMemcpyAsync(s->h_idx, s->d_idx, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                   ctx->stream));
     RN_HIP_TRY(ctx, hipEventRecord(s->done, ctx->stream));
     s->busy = 1;
+    s->n = n;
     ++p->head;
+    return RN_OK;
+}
+
+int rn_pipeline_submit(rn_pipeline *p, const float *host_input_nchw)
+{
+    return p ? rn_pipeline_submit_n(p, host_input_nchw, p->B) : RN_ERR_INVALID;
+}
+
+int rn_pipeline_collect_n(rn_pipeline *p, float *host_logits, uint64_t *host_top1, uint64_t *n)
+{
+    if (!p) return RN_ERR_INVALID;
+    rn_ctx *ctx = p->ctx;
+    if (p->head == p->tail)
+        return rn_set_error(ctx, RN_ERR_INVALID, "rn_pipeline_collect: nothing in flight");
+    rn_pipeline_slot *s = &p->slot[p->tail & 1];
+    RN_TRY(rn_bind_device(ctx));
+    RN_HIP_TRY(ctx, hipEventSynchronize(s->done));
+    if (host_logits) memcpy(host_logits, s->h_out, (size_t)s->n * 1000 * sizeof(float));
+    if (host_top1) memcpy(host_top1, s->h_idx, (size_t)s->n * sizeof(uint64_t));
+    if (n) *n = s->n;
+    s->busy = 0;
+    ++p->tail;
     return RN_OK;
 }
 
 int rn_pipeline_collect(rn_pipeline *p, float *host_logits)
 {
     if (!p || !host_logits) return RN_ERR_INVALID;
-    rn_ctx *ctx = p->ctx;
-    if (p->head == p->tail)
-        return rn_set_error(ctx, RN_ERR_INVALID, "rn_pipeline_collect: nothing in flight");
-    rn_pipeline_slot *s = &p->slot[p->tail & 1];
-    RN_HIP_TRY(ctx, hipEventSynchronize(s->done));
-    memcpy(host_logits, s->h_out, (size_t)p->B * 1000 * sizeof(float));
-    s->busy = 0;
-    ++p->tail;
-    return RN_OK;
+    return rn_pipeline_collect_n(p, host_logits, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -24,7 +24,11 @@
 #define RN_CLASSES 1000
 
 enum { JOB_NONE = 0, JOB_CREATE, JOB_SET_TENSOR, JOB_LOAD_DIR, JOB_SET_DTYPE, JOB_FINALIZE,
-       JOB_FORWARD, JOB_TUNE, JOB_QUIT };
+       JOB_FORWARD, JOB_TUNE, JOB_STREAM_OPEN, JOB_SUBMIT, JOB_COLLECT, JOB_STREAM_CLOSE, JOB_QUIT };
+
+/* A shard's images go through the device in chunks of at most this many: the upload of chunk
+ * i+1 (pinned staging, copy stream) runs beside the forward of chunk i (rn_pipeline_*). */
+#define RN_SHARD_CHUNK 256
 
 typedef struct rn_shard_worker {
     struct rn_shard *group;
@@ -33,9 +37,14 @@ typedef struct rn_shard_worker {
     int rank, device;
     rn_ctx *ctx;
     rn_model *model;
-    float *d_in, *d_logits;
-    uint64_t *d_idx;
+    float *d_in, *d_logits; /* tuning only: the forward itself runs out of the pipeline's slots */
     uint64_t cap; /* images the device buffers hold */
+    /* pinned staging + copy stream + two slots on this device: upload, forward and download of
+     * consecutive chunks (rn_shard_forward) or batches (rn_shard_submit / _collect) overlap */
+    rn_pipeline *pipe;
+    uint64_t pipe_B;
+    int pipe_mode;
+    uint64_t stream_lo, stream_hi; /* streaming form: this shard's image range of every batch */
     uint64_t seen; /* last job sequence number this worker ran */
     int status;
     char err[512];
@@ -56,6 +65,8 @@ struct rn_shard {
     float *logits;
     uint64_t *top1;
     int ivalue; /* dtype or mode */
+    uint64_t stream_B;    /* streaming form: batch size of rn_shard_stream_open, 0 = closed */
+    int stream_in_flight; /* batches submitted and not yet collected (0..2) */
     char err[640];
 };
 
@@ -85,14 +96,35 @@ static int ensure_buffers(rn_shard_worker *w, uint64_t nb)
     if (nb <= w->cap) return RN_OK;
     if (w->d_in) rn_free(w->ctx, w->d_in);
     if (w->d_logits) rn_free(w->ctx, w->d_logits);
-    if (w->d_idx) rn_free(w->ctx, w->d_idx);
     w->d_in = w->d_logits = NULL;
-    w->d_idx = NULL;
     w->cap = 0;
     WTRY(w, rn_malloc(w->ctx, (void **)&w->d_in, nb * IMG_FLOATS * sizeof(float)));
     WTRY(w, rn_malloc(w->ctx, (void **)&w->d_logits, nb * RN_CLASSES * sizeof(float)));
-    WTRY(w, rn_malloc(w->ctx, (void **)&w->d_idx, nb * sizeof(uint64_t)));
     w->cap = nb;
+    return RN_OK;
+}
+
+/* the worker's pipeline for batches of up to B images in `mode` (rebuilt when either changes) */
+static int ensure_pipeline(rn_shard_worker *w, uint64_t B, int mode)
+{
+    if (w->pipe && w->pipe_B >= B && w->pipe_mode == mode) return RN_OK;
+    if (w->pipe) {
+        if (rn_pipeline_in_flight(w->pipe) > 0)
+            return fail(w, RN_ERR_INVALID, "batches still in flight: collect them first");
+        rn_pipeline_destroy(w->pipe);
+        w->pipe = NULL;
+    }
+    WTRY(w, rn_pipeline_create(w->model, &w->pipe, B, mode));
+    w->pipe_B = B;
+    w->pipe_mode = mode;
+    return RN_OK;
+}
+
+/* one collected chunk goes to rows [at, at + n) of the caller's arrays */
+static int collect_chunk(rn_shard_worker *w, const struct rn_shard *g, uint64_t at, uint64_t *n)
+{
+    WTRY(w, rn_pipeline_collect_n(w->pipe, g->logits ? g->logits + at * RN_CLASSES : NULL,
+                                  g->top1 ? g->top1 + at : NULL, n));
     return RN_OK;
 }
 
@@ -115,34 +147,69 @@ static int run_job(rn_shard_worker *w, const struct rn_shard *g)
     case JOB_FINALIZE:
         WTRY(w, rn_model_finalize(w->model));
         return RN_OK;
-    case JOB_FORWARD:
     case JOB_TUNE: {
         uint64_t lo, hi, nb;
         rn_shard_bounds(g->numel, w->rank, g->n, &lo, &hi);
         nb = hi - lo;
+        if (nb > RN_SHARD_CHUNK) nb = RN_SHARD_CHUNK; /* the launches rn_shard_forward issues */
         if (nb == 0) return RN_OK;
         WTRY(w, ensure_buffers(w, nb));
-        /* upload of this shard's images, forward, download of its logits / class indices:
-         * all on this device's stream, beside the other devices' */
         WTRY(w, rn_memcpy_h2d(w->ctx, w->d_in, g->tensor + lo * IMG_FLOATS,
                               nb * IMG_FLOATS * sizeof(float)));
-        if (g->kind == JOB_TUNE) {
-            WTRY(w, rn_model_tune(w->model, w->d_in, nb, w->d_logits, g->ivalue));
-            WTRY(w, rn_sync(w->ctx));
-            return RN_OK;
-        }
-        WTRY(w, rn_model_forward(w->model, w->d_in, nb, w->d_logits, g->ivalue));
-        if (g->top1) {
-            /* first maximum wins, as the reference's host loop (main.cu:243-249) */
-            WTRY(w, rn_argmax_forward(w->ctx, w->d_logits, w->d_idx, nb, RN_CLASSES));
-            WTRY(w, rn_memcpy_d2h(w->ctx, g->top1 + lo, w->d_idx, nb * sizeof(uint64_t)));
-        }
-        if (g->logits)
-            WTRY(w, rn_memcpy_d2h(w->ctx, g->logits + lo * RN_CLASSES, w->d_logits,
-                                  nb * RN_CLASSES * sizeof(float)));
+        WTRY(w, rn_model_tune(w->model, w->d_in, nb, w->d_logits, g->ivalue));
         WTRY(w, rn_sync(w->ctx));
         return RN_OK;
     }
+    case JOB_FORWARD: {
+        /* this shard's images in chunks through the device's pipeline, two in flight: chunk i+1
+         * is copied into pinned staging and uploaded on the copy stream while chunk i runs;
+         * logits and class indices (first maximum wins, main.cu:243-249) come back per chunk */
+        uint64_t lo, hi, sent, got, n;
+        rn_shard_bounds(g->numel, w->rank, g->n, &lo, &hi);
+        if (hi == lo) return RN_OK;
+        WTRY(w, ensure_pipeline(w, hi - lo < RN_SHARD_CHUNK ? hi - lo : RN_SHARD_CHUNK, g->ivalue));
+        if (rn_pipeline_in_flight(w->pipe) > 0)
+            return fail(w, RN_ERR_INVALID, "rn_shard_forward while submitted batches are in flight");
+        for (sent = got = lo; got < hi;) {
+            if (sent < hi && rn_pipeline_in_flight(w->pipe) < 2) {
+                n = hi - sent < RN_SHARD_CHUNK ? hi - sent : RN_SHARD_CHUNK;
+                WTRY(w, rn_pipeline_submit_n(w->pipe, g->tensor + sent * IMG_FLOATS, n));
+                sent += n;
+                continue;
+            }
+            {
+                const int st = collect_chunk(w, g, got, &n);
+                if (st != RN_OK) return st;
+            }
+            got += n;
+        }
+        return RN_OK;
+    }
+    case JOB_STREAM_OPEN: {
+        rn_shard_bounds(g->numel, w->rank, g->n, &w->stream_lo, &w->stream_hi);
+        if (w->stream_hi == w->stream_lo) return RN_OK;
+        WTRY(w, ensure_pipeline(w, w->stream_hi - w->stream_lo, g->ivalue));
+        return RN_OK;
+    }
+    case JOB_SUBMIT: {
+        const uint64_t nb = w->stream_hi - w->stream_lo;
+        if (nb == 0) return RN_OK;
+        if (!w->pipe) return fail(w, RN_ERR_INVALID, "rn_shard_submit before rn_shard_stream_open");
+        /* NULL: the caller filled the pinned staging buffers (rn_shard_stream_buffer) in place */
+        WTRY(w, rn_pipeline_submit_n(w->pipe, g->tensor ? g->tensor + w->stream_lo * IMG_FLOATS : NULL, nb));
+        return RN_OK;
+    }
+    case JOB_COLLECT: {
+        uint64_t n;
+        if (w->stream_hi == w->stream_lo) return RN_OK;
+        if (!w->pipe) return fail(w, RN_ERR_INVALID, "rn_shard_collect before rn_shard_stream_open");
+        return collect_chunk(w, g, w->stream_lo, &n);
+    }
+    case JOB_STREAM_CLOSE:
+        if (w->pipe) rn_pipeline_destroy(w->pipe);
+        w->pipe = NULL;
+        w->stream_lo = w->stream_hi = 0;
+        return RN_OK;
     default:
         return RN_OK;
     }
@@ -151,10 +218,11 @@ static int run_job(rn_shard_worker *w, const struct rn_shard *g)
 static void release_device_state(rn_shard_worker *w)
 {
     if (w->ctx) {
+        if (w->pipe) rn_pipeline_destroy(w->pipe);
         if (w->d_in) rn_free(w->ctx, w->d_in);
         if (w->d_logits) rn_free(w->ctx, w->d_logits);
-        if (w->d_idx) rn_free(w->ctx, w->d_idx);
     }
+    w->pipe = NULL;
     if (w->model) rn_model_destroy(w->model);
     if (w->ctx) rn_ctx_destroy(w->ctx);
     w->model = NULL;
@@ -320,6 +388,8 @@ static int forward_like(rn_shard *g, int kind, const float *host_input_nchw, uin
 int rn_shard_forward(rn_shard *g, const float *host_input_nchw, uint64_t B, float *host_logits,
                      uint64_t *host_top1, int mode)
 {
+    if (g && g->stream_in_flight > 0) return RN_ERR_INVALID; /* collect the submitted batches first */
+    if (g) g->stream_B = 0; /* the per-device pipelines are re-sized for this call's chunks */
     return forward_like(g, JOB_FORWARD, host_input_nchw, B, host_logits, host_top1, mode);
 }
 
@@ -327,3 +397,59 @@ int rn_shard_tune(rn_shard *g, const float *host_input_nchw, uint64_t B, int mod
 {
     return forward_like(g, JOB_TUNE, host_input_nchw, B, NULL, NULL, mode);
 }
+
+/* ---- streaming form: consecutive batches of B images, two in flight per device ---------- */
+int rn_shard_stream_open(rn_shard *g, uint64_t B, int mode)
+{
+    if (!g || B == 0) return RN_ERR_INVALID;
+    g->numel = B;
+    g->ivalue = mode;
+    g->stream_B = B;
+    g->stream_in_flight = 0;
+    return post(g, JOB_STREAM_OPEN);
+}
+
+int rn_shard_stream_close(rn_shard *g)
+{
+    if (!g) return RN_ERR_INVALID;
+    g->stream_B = 0;
+    g->stream_in_flight = 0;
+    return post(g, JOB_STREAM_CLOSE);
+}
+
+int rn_shard_stream_buffer(rn_shard *g, int rank, float **host_staging, uint64_t *lo, uint64_t *hi)
+{
+    rn_shard_worker *w;
+    if (!g || rank < 0 || rank >= g->n || !host_staging) return RN_ERR_INVALID;
+    w = &g->w[rank];
+    *host_staging = NULL;
+    if (lo) *lo = w->stream_lo;
+    if (hi) *hi = w->stream_hi;
+    if (g->stream_B == 0) return RN_ERR_INVALID;
+    if (w->stream_hi == w->stream_lo) return RN_OK; /* an empty shard has no staging */
+    /* between jobs the worker is parked: reading its pipeline from the caller's thread is safe */
+    return rn_pipeline_input_buffer(w->pipe, host_staging);
+}
+
+int rn_shard_submit(rn_shard *g, const float *host_input_nchw)
+{
+    int st;
+    if (!g || g->stream_B == 0 || g->stream_in_flight >= 2) return RN_ERR_INVALID;
+    g->tensor = host_input_nchw;
+    st = post(g, JOB_SUBMIT);
+    if (st == RN_OK) ++g->stream_in_flight;
+    return st;
+}
+
+int rn_shard_collect(rn_shard *g, float *host_logits, uint64_t *host_top1)
+{
+    int st;
+    if (!g || g->stream_B == 0 || g->stream_in_flight == 0) return RN_ERR_INVALID;
+    g->logits = host_logits;
+    g->top1 = host_top1;
+    st = post(g, JOB_COLLECT);
+    if (st == RN_OK) --g->stream_in_flight;
+    return st;
+}
+
+int rn_shard_in_flight(const rn_shard *g) { return g ? g->stream_in_flight : 0; }

@@ -432,6 +432,10 @@ static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, 
     if (B == 0) return RN_OK;
     RN_REQUIRE(ctx, dtype == RN_DTYPE_F32 || dtype == RN_DTYPE_BF16, "unknown dtype");
     RN_REQUIRE(ctx, inp && out && packed_weight && inp != out, "null or aliased tensor");
+    // the pool is an unsigned-integer maximum of float bit patterns into rows that start at 0:
+    // only right for values >= 0, i.e. behind the ReLU (a negative value would win as an integer)
+    RN_REQUIRE(ctx, relu != 0, "the fused stem + max-pool needs the ReLU (relu = 1); without it use "
+                               "rn_conv2d_nhwc_forward_dt + rn_maxpool2d_nhwc_forward_dt");
     RN_REQUIRE(ctx, Hp >= 7 && Wp >= 7 && Hp < (1u << 14) && Wp < (1u << 14), "image size out of range");
     const uint64_t Ho = rn_conv_output_size(Hp, 7, 2, 0), Wo = rn_conv_output_size(Wp, 7, 2, 0);
     const uint64_t PH = rn_conv_output_size(Ho, 3, 2, 1), PW = rn_conv_output_size(Wo, 3, 2, 1);

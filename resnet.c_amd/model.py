@@ -274,8 +274,10 @@ class NativeModel:
         return int(L.lib().rn_model_get_streams(self.handle))
 
     def set_chain(self, on: bool) -> None:
-        """Fused bf16 mode: conv3 of a 64-channel block + conv1 of the next block as one launch
-        (default on; the same bits either way)."""
+        """Fused mode: conv3 of a bottleneck block + conv1 of the next block as one launch wherever
+        a chain kernel exists (fp32: the 64-channel blocks of stage 1; bf16: those and the
+        128-channel blocks of stage 2; rn_model.c chain_applies).  Default on; the same bits
+        either way."""
         L.check(L.lib().rn_model_set_chain(self.handle, int(on)), "rn_model_set_chain")
 
     def set_stem_pool_fusion(self, on) -> None:
@@ -339,6 +341,7 @@ class ShardedModel:
         h = ctypes.c_void_p()
         L.check(lib.rn_shard_create(ctypes.byref(h), dev, len(devices), ARCH_ID[arch]), "rn_shard_create")
         self.handle, self.n = h, len(devices)
+        self._stream_B = 0
         if weights_dir is not None:
             self._check(lib.rn_shard_load_dir(h, weights_dir.encode()), "rn_shard_load_dir")
         else:
@@ -380,6 +383,43 @@ class ShardedModel:
         self._check(L.lib().rn_shard_tune(self.handle, x.ctypes.data, x.shape[0],
                                           L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS),
                     "rn_shard_tune")
+
+    # streaming form: consecutive batches of B images, two in flight on every device
+    def stream_open(self, B: int, fused: bool = True) -> None:
+        self._check(L.lib().rn_shard_stream_open(self.handle, B, L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS),
+                    "rn_shard_stream_open")
+        self._stream_B = B
+
+    def stream_buffer(self, rank: int):
+        """(pinned staging of shard `rank` for the next submit as [hi-lo,3,224,224], lo, hi)."""
+        ptr, lo, hi = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(L.lib().rn_shard_stream_buffer(self.handle, rank, ctypes.byref(ptr), ctypes.byref(lo),
+                                                   ctypes.byref(hi)), "rn_shard_stream_buffer")
+        n = hi.value - lo.value
+        if n == 0:
+            return None, lo.value, hi.value
+        buf = (ctypes.c_float * (n * 3 * 224 * 224)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.float32).reshape(n, 3, 224, 224), lo.value, hi.value
+
+    def submit(self, x: Optional[np.ndarray] = None) -> None:
+        ptr = None
+        if x is not None:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            assert self._stream_B == 0 or x.shape == (self._stream_B, 3, 224, 224)
+            ptr = x.ctypes.data
+        self._check(L.lib().rn_shard_submit(self.handle, ptr), "rn_shard_submit")
+
+    def collect(self) -> Tuple[np.ndarray, np.ndarray]:
+        logits = np.empty((self._stream_B, 1000), dtype=np.float32)
+        top1 = np.empty(self._stream_B, dtype=np.uint64)
+        self._check(L.lib().rn_shard_collect(self.handle, logits.ctypes.data, top1.ctypes.data), "rn_shard_collect")
+        return logits, top1
+
+    def in_flight(self) -> int:
+        return int(L.lib().rn_shard_in_flight(self.handle))
+
+    def stream_close(self) -> None:
+        self._check(L.lib().rn_shard_stream_close(self.handle), "rn_shard_stream_close")
 
     def close(self) -> None:
         if self.handle:
@@ -445,19 +485,27 @@ class Pipeline:
         return np.frombuffer(buf, dtype=np.float32).reshape(self.batch, 3, 224, 224)
 
     def submit(self, x: np.ndarray | None = None) -> None:
-        ptr = None
+        """x: [n,3,224,224] with n <= batch (a ragged last batch), or None when the staging
+        buffer was filled in place (a whole batch)."""
+        ptr, n = None, self.batch
         if x is not None:
             x = np.ascontiguousarray(x, dtype=np.float32)
-            assert x.shape == (self.batch, 3, 224, 224)
-            ptr = x.ctypes.data
-        L.check(L.lib().rn_pipeline_submit(self.handle, ptr), "rn_pipeline_submit",
+            assert x.shape[1:] == (3, 224, 224)
+            ptr, n = x.ctypes.data, x.shape[0]
+        L.check(L.lib().rn_pipeline_submit_n(self.handle, ptr, n), "rn_pipeline_submit_n",
                 self.model.ctx.handle)
 
     def collect(self) -> np.ndarray:
+        return self.collect_top1()[0]
+
+    def collect_top1(self):
+        """(logits [n,1000], class indices [n]) of the oldest batch in flight."""
         out = np.empty((self.batch, 1000), dtype=np.float32)
-        L.check(L.lib().rn_pipeline_collect(self.handle, out.ctypes.data), "rn_pipeline_collect",
-                self.model.ctx.handle)
-        return out
+        idx = np.empty(self.batch, dtype=np.uint64)
+        n = ctypes.c_uint64()
+        L.check(L.lib().rn_pipeline_collect_n(self.handle, out.ctypes.data, idx.ctypes.data, ctypes.byref(n)),
+                "rn_pipeline_collect_n", self.model.ctx.handle)
+        return out[:n.value], idx[:n.value]
 
     def in_flight(self) -> int:
         return int(L.lib().rn_pipeline_in_flight(self.handle))

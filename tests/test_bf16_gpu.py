@@ -425,6 +425,37 @@ def test_bf16_unsupported_shapes_are_reported_not_guessed():
     assert e.value.status == L.RN_ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_chain_refuses_misaligned_or_aliased_tensors(dtype):
+    """rn_conv_chain_forward_dt moves 16-byte pieces and reads rows ahead of the rows it writes:
+    a pointer off a 16-byte boundary or an output on top of an input is a status, not a launch."""
+    from resnet_c_amd import _lib as L
+    from resnet_c_amd.tensor import _DeviceBuffer
+    ctx, lib = R.get_ctx(), L.lib()
+    dt, es = (L.RN_DTYPE_BF16, 2) if dtype == "bf16" else (L.RN_DTYPE_F32, 4)
+    rows = 128
+    t2, x, y, t1 = (_DeviceBuffer(ctx, rows * c * es + 64) for c in (64, 256, 256, 64))
+    w3, w1 = _DeviceBuffer(ctx, 64 * 256 * es + 64), _DeviceBuffer(ctx, 256 * 64 * es + 64)
+    sc = _DeviceBuffer(ctx, 256 * 4 + 64)
+
+    def call(t2p, xp, yp, t1p, w3p=w3.ptr, scp=None):
+        return lib.rn_conv_chain_forward_dt(ctx.handle, dt, t2p, xp, yp, w3p, scp, None, t1p, w1.ptr, None, None,
+                                            rows, 64, 256, 64)
+
+    for c in (t2, x, y, t1, w3, w1):
+        L.check(lib.rn_memset(ctx.handle, c.ptr, 0, c.nbytes), "memset", ctx.handle)
+    assert call(t2.ptr, x.ptr, y.ptr, t1.ptr) == L.RN_OK
+    ctx.sync()
+    assert call(t2.ptr + 8, x.ptr, y.ptr, t1.ptr) == L.RN_ERR_INVALID      # misaligned input
+    assert call(t2.ptr, x.ptr, y.ptr + 4, t1.ptr) == L.RN_ERR_INVALID      # misaligned output
+    assert call(t2.ptr, x.ptr, y.ptr, t1.ptr, w3p=w3.ptr + 2) == L.RN_ERR_INVALID
+    assert call(t2.ptr, x.ptr, y.ptr, t1.ptr, scp=sc.ptr + 4) == L.RN_ERR_INVALID
+    assert call(t2.ptr, x.ptr, x.ptr, t1.ptr) == L.RN_ERR_INVALID          # y on top of the residual
+    assert call(t2.ptr, x.ptr, y.ptr, t2.ptr) == L.RN_ERR_INVALID          # t1 on top of t2
+    assert call(t2.ptr, x.ptr, y.ptr, y.ptr) == L.RN_ERR_INVALID           # t1 on top of y
+    assert b"alias" in lib.rn_last_error(ctx.handle)
+
+
 def test_bf16_model_agrees_with_fp32_model(state50, finch, golden_dir):
     m32 = R.NativeModel("resnet50", state=state50)
     m16 = R.NativeModel("resnet50", state=state50, dtype="bf16")

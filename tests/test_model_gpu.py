@@ -695,3 +695,159 @@ def test_two_host_threads_two_contexts(state50):
         t.join()
     assert not errors, errors
     assert np.array_equal(np.concatenate(results), want)
+
+
+def test_config3_bf16_b2048_as_eight_shards_on_one_device(state50, model50):
+    """BASELINE.json configs[3] end to end, rehearsed on ONE device: ResNet-50 bf16, global batch
+    2048 = 8 shards x 256 (rn_shard_* over devices 0 x 8: eight host threads, contexts and models).
+    Every shard's rows must be the bits of a single bf16 B=256 forward of the same images; and
+    SURVEY 8(d)'s parity bar for this config is measured over ALL 2048 images: top-1 agreement
+    with the fp32 engine >= 99 %, with the observed rate, the logit error and the margins of the
+    disagreeing images printed (DESIGN.md section 3 quotes them)."""
+    B, G = 2048, 8
+    x = R.weights.generate_input(B, seed=2048)
+    sh = R.ShardedModel([0] * G, "resnet50", state=state50, dtype="bf16")
+    try:
+        logits, top1 = sh.forward(x, fused=True)
+    finally:
+        sh.close()
+    assert logits.shape == (B, 1000) and np.isfinite(logits).all()
+    assert np.array_equal(top1, logits.argmax(1).astype(np.uint64))   # first maximum wins == numpy
+    one = R.NativeModel("resnet50", state=state50, dtype="bf16")
+    try:
+        for r in range(G):
+            lo, hi = R.ShardedModel.bounds(B, r, G)
+            assert (lo, hi) == (256 * r, 256 * r + 256)
+            assert np.array_equal(one.forward(x[lo:hi], fused=True), logits[lo:hi]), r
+    finally:
+        one.close()
+    f32 = np.concatenate([model50.forward(x[i:i + 256], fused=True) for i in range(0, B, 256)])
+    agree = logits.argmax(1) == f32.argmax(1)
+    rate = float(agree.mean())
+    err = np.abs(logits - f32)
+    top2 = np.sort(f32, axis=1)[:, -2:]
+    margin = top2[:, 1] - top2[:, 0]
+    rel = float(np.linalg.norm(logits - f32) / np.linalg.norm(f32))
+    print(f"\nconfigs[3] rehearsal: bf16 vs fp32 top-1 agreement {int(agree.sum())}/{B} = {rate:.4%}; "
+          f"max|dlogit| {err.max():.4f}, mean {err.mean():.5f}, relative L2 {rel:.3e}; logits range "
+          f"[{f32.min():.2f}, {f32.max():.2f}]; fp32 top-2 margins of the disagreeing images: "
+          f"{np.sort(margin[~agree])[:12].round(4).tolist()} (median margin of all images {np.median(margin):.3f})")
+    assert err.max() <= 0.25
+    # a disagreement can only sit where the fp32 margin is below twice the logit error
+    assert (margin[~agree] <= 2 * err.max()).all()
+    assert rate >= 0.99, rate
+
+
+def test_sharded_stream_keeps_two_batches_in_flight(state50, model50, finch):
+    """rn_shard_stream_*: pinned staging + copy stream + two slots on every device (the composition
+    of rn_shard_* with rn_pipeline_*): consecutive batches, two in flight, rows in image order,
+    the bits of the plain forward; the staging buffers can be filled in place; protocol errors
+    are statuses."""
+    B = 10
+    xs = [R.weights.generate_input(B, seed=300 + i) for i in range(4)]
+    xs[1][7] = finch[0]
+    want = [model50.forward(x, fused=True) for x in xs]
+    g = R.ShardedModel([0, 0, 0], "resnet50", state=state50)
+    try:
+        with pytest.raises(R.RnError):
+            g.submit(xs[0])                      # not opened yet
+        g.stream_open(B, fused=True)
+        g.submit(xs[0]); g.submit(xs[1])
+        assert g.in_flight() == 2
+        with pytest.raises(R.RnError):
+            g.submit(xs[2])                      # both slots busy
+        l0, t0 = g.collect()
+        assert np.array_equal(l0, want[0]) and np.array_equal(t0, R.ops.argmax(want[0]))
+        # zero-copy: write shard r's images into its pinned staging buffer, submit nothing
+        for r in range(3):
+            buf, lo, hi = g.stream_buffer(r)
+            assert (lo, hi) == R.ShardedModel.bounds(B, r, 3) and buf.shape[0] == hi - lo
+            buf[...] = xs[2][lo:hi]
+        g.submit(None)
+        l1, t1 = g.collect()
+        assert np.array_equal(l1, want[1]) and int(t1[7]) == 112
+        l2, _ = g.collect()
+        assert np.array_equal(l2, want[2])
+        with pytest.raises(R.RnError):
+            g.collect()                          # nothing in flight
+        # the one-shot call still works afterwards (it re-sizes the pipelines), and a shard larger
+        # than the 256-image chunk goes through in several chunks
+        l3, t3 = g.forward(xs[3], fused=True)
+        assert np.array_equal(l3, want[3]) and np.array_equal(t3, R.ops.argmax(want[3]))
+        g.stream_close()
+    finally:
+        g.close()
+    big = np.concatenate([xs[0]] * 30)[:290]     # one device, 290 images: chunks of 256 + 34
+    g = R.ShardedModel([0], "resnet50", state=state50)
+    try:
+        lb, tb = g.forward(big, fused=True)
+        assert np.array_equal(lb[:10], want[0]) and np.array_equal(lb[280:290], want[0])
+        assert np.array_equal(tb, lb.argmax(1).astype(np.uint64))
+    finally:
+        g.close()
+
+
+def test_pipeline_ragged_batch_and_class_indices(model50, finch):
+    """rn_pipeline_submit_n / _collect_n: a last batch with fewer images than the pipeline's B, and
+    the class indices (first maximum wins, main.cu:243-249) next to the logits."""
+    B = 4
+    x = R.weights.generate_input(B, seed=77)
+    x[1] = finch[0]
+    want = model50.forward(x, fused=True)
+    pipe = R.Pipeline(model50, B, fused=True)
+    try:
+        pipe.submit(x); pipe.submit(x[:3])
+        l0, t0 = pipe.collect_top1()
+        l1, t1 = pipe.collect_top1()
+        assert np.array_equal(l0, want) and np.array_equal(t0, R.ops.argmax(want)) and int(t0[1]) == 112
+        assert l1.shape == (3, 1000) and np.array_equal(l1, want[:3]) and np.array_equal(t1, t0[:3])
+        with pytest.raises(R.RnError):
+            pipe.submit(np.concatenate([x, x]))   # more images than the slots hold
+    finally:
+        pipe.close()
+
+
+def test_live_graph_pins_the_scratch_of_every_stream(state50):
+    """With the batch split over several streams the captured nodes also point into the scratch of
+    the model's secondary contexts: a later eager forward that would have to grow one of those
+    (fewer, larger parts at the same B) must be refused -- or leave the replay's bits alone --
+    never free memory the graph still uses."""
+    ctx = R.Context(0)
+    m = R.NativeModel("resnet50", state=state50, ctx=ctx)
+    try:
+        B = 256
+        m.set_streams(4)
+        x = R.weights.generate_input(B, seed=17)
+        want = m.forward(x, fused=True)
+        xd = R.FloatTensor.from_numpy(x, R.Device.GPU)
+        out = R.FloatTensor((B, 1000), R.Device.GPU)
+        g = R.Graph(m, xd.data(), B, out.data(), True)
+        m.set_streams(2)                 # parts of 128 instead of 64 on the second context
+        try:
+            eager = m.forward(x, fused=True)
+            assert np.array_equal(eager, want)
+        except R.RnError:
+            pass                         # refused: the pinned scratch would have had to grow
+        R._lib.check(R._lib.lib().rn_memset(ctx.handle, out.data(), 0, B * 4000), "memset", ctx.handle)
+        g.launch(); ctx.sync()
+        assert np.array_equal(out.numpy(), want)
+        g.close()
+        assert np.array_equal(m.forward(x, fused=True), want)   # unpinned again
+    finally:
+        m.close()
+        ctx.close()
+
+
+def test_plain_c_driver_names_the_fixed_geometry(state50, tmp_path):
+    """rn_model_forward has no size argument (224 x 224 like main.cu:230): rn_infer checks the file's
+    element count and says what the driver takes instead of reading a wrong-sized image."""
+    wdir = tmp_path / "weights_bin"
+    os.mkdir(wdir)
+    R.weights.save_weights_bin(state50, str(wdir))
+    inp = tmp_path / "small.bin"
+    R.weights.generate_input(1, seed=1, hw=160).tofile(inp)
+    exe = os.path.join(os.path.dirname(R._lib.LIB_PATH), "rn_infer")
+    for extra in (["--device", "0"], ["--devices", "0,0"]):
+        r = subprocess.run([exe, "--arch", "50", "--weights", str(wdir), "--input", str(inp), "--batch", "1"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "3 x 224 x 224" in r.stderr and "unsupported" in r.stderr, r.stderr

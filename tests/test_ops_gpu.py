@@ -526,6 +526,15 @@ def test_packed_weight_cache_of_the_nchw_route():
         got2 = run()
         assert_close(got2, O.conv2d(x, w2, 1, 1), 64 * 9)
         assert not np.array_equal(got2, plain1)
+        # a write that starts INSIDE the cached buffer (its second half) stales the panel as well
+        half = w2.size // 2
+        w3 = w2.copy().reshape(-1)
+        w3[half:] = w1.reshape(-1)[half:]
+        L.check(lib.rn_memcpy_h2d(ctx.handle, wd.data() + 4 * half, w3[half:].ctypes.data, 4 * (w3.size - half)),
+                "h2d", ctx.handle)
+        got3 = run()
+        assert_close(got3, O.conv2d(x, w3.reshape(w2.shape), 1, 1), 64 * 9)
+        assert not np.array_equal(got3, got2)
         del wd                                     # rn_free of a cached weight buffer
         wd = R.FloatTensor.from_numpy(w1, R.Device.GPU)
         assert np.array_equal(run(), plain1)
@@ -670,3 +679,10 @@ def test_fused_stem_refuses_what_it_cannot_do():
         ops.stem_pool(x, w)
     with pytest.raises(L.RnError):
         ops.stem_pool(x, w, from_nchw=True)
+    # without the ReLU the integer maximum of the pool would be wrong for negative values: refused
+    x = rnd((1, 3, 32, 32), 7)
+    for nchw in (False, True):
+        for bf16 in (False, True):
+            with pytest.raises(L.RnError) as e:
+                ops.stem_pool(x, w, None, None, False, bf16=bf16, from_nchw=nchw)
+            assert e.value.status == L.RN_ERR_INVALID and "ReLU" in str(e.value)
