@@ -165,6 +165,11 @@ int rn_ctx_create(rn_ctx **out, int device, void *hip_stream)
     rn_ctx *ctx = (rn_ctx *)calloc(1, sizeof(rn_ctx));
     if (!ctx) return RN_ERR_NOMEM;
     ctx->device = device;
+    ctx->cus = 256;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) ctx->cus = v;
+    }
     ctx->layout = RN_LAYOUT_NCHW;
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;

@@ -16,6 +16,7 @@ struct rn_wcache_entry {
 
 struct rn_ctx {
     int device;
+    int cus;  // compute units of the device (256 on MI355X), asked once at creation
     hipStream_t stream;
     bool own_stream;
     int layout;

@@ -8,30 +8,35 @@
 // on 0.38 / 0.08 ms of matrix work), after which its 112x112x64 output -- the largest tensor of
 // the network -- goes to HBM only to be read back by the pool.  Here:
 //
-//  * a block owns two pooled rows of one image: stem rows 2*ph0-1 .. 2*ph0+3 (five rows, one of
-//    them a halo recomputed by the next block: +25 % matrix work) x all columns x 64 channels;
-//  * the input patch those rows need -- 15 rows of the physically padded NHWC image, one
+//  * a block walks DOWN one image (or a contiguous segment of it) in items of four stem rows =
+//    two pooled rows: stem rows 4j .. 4j+3 x all columns x 64 channels.  The pool windows
+//    overlap by one stem row (pooled row 2j+2 also needs stem row 4j+3): instead of computing
+//    that row twice (the round-2 kernel owned five rows per item, +25 % matrix work) its maxima
+//    go into the pooled row of the NEXT item, which lives in the same block's LDS -- a ring of
+//    five pooled rows.  Only a segment that starts inside an image computes the one stem row
+//    above it once more (the "halo tile", one row in 4 * seg_len);
+//  * the input patch an item needs -- 13 rows of the physically padded NHWC image, one
 //    contiguous block of memory -- is copied to LDS once; the MFMA A operands are read
 //    straight out of it: for fixed kernel row, the k index runs over (kw, c) = consecutive
 //    floats / bf16 of the patch row, so a fragment is one ds_read_b32 (fp32, 32x32x2 MFMA) or
 //    one ds_read_b128 (bf16, 32x32x16 MFMA) at base(position) + constant(k-step).  No im2col;
-//  * the weights live in registers for the lifetime of the (persistent) block: 77 floats or
-//    14 x 8 bf16 per lane, one 32-channel half per wave;
+//  * the weights live in registers for the lifetime of the block: 77 floats or 14 x 8 bf16 per
+//    lane, one 32-channel half per wave;
 //  * K order: kernel row major; fp32 (kw, c) with one zero-weight slot per row (22 per row, 154);
 //    bf16 (kw pair, kw parity, c of 4) with kw = 7 and c = 3 zero-weight (32 per row, 224);
-//  * epilogue in registers: y = max(acc * scale + shift, 0) (bf16: rounded to bf16), then the
-//    max-pool: the vertical part in registers (an M tile is 4 stem rows x 8 columns, so a lane
-//    holds four rows of four adjacent columns of its channel), the rest as LDS integer maxima:
-//    y >= 0, so its bit pattern orders like the value and ds_max_u32 into a zeroed [2][PW][64]
-//    buffer gives exactly the reference's maximum over the window's real pixels (every window
-//    has one; padded taps are skipped, ops.cu:65-67);
+//  * a wave multiplies its M tiles (4 stem rows x 8 columns each) ONE AFTER THE OTHER, and the
+//    register epilogue of tile j -- y = max(acc * scale + shift, 0) (bf16: rounded to bf16), the
+//    vertical part of the pool (a lane holds four rows of four adjacent columns of its channel),
+//    the rest as LDS integer maxima: y >= 0, so its bit pattern orders like the value and
+//    ds_max_u32 into the zeroed ring gives exactly the reference's maximum over the window's real
+//    pixels (every window has one; padded taps are skipped, ops.cu:65-67) -- sits in the
+//    instruction stream of tile j+1's MFMA chain, whose matrix work covers it (the round-2
+//    kernel ran all tiles' chains first and then 80 values per lane of epilogue with the matrix
+//    pipe idle: 0.09 of its 0.68 / 0.22 ms);
 //  * the pooled rows leave as whole 128..256-byte pixels.  The stem tensor is never written.
 //
-// Bound: matrix pipe in fp32 (0.52 ms at peak for B=256 with the halo), HBM in bf16 (0.3 GB).
-// Measured at B=256 (timing-only builds with parts switched off): fp32 0.68 ms = 0.57 matrix
-// phase + 0.09 epilogue arithmetic (of which 0.01 the LDS maxima) + 0.02 the rest; bf16 0.22 ms =
-// 0.11 + 0.09 + 0.02: the register epilogue (80 values per lane: affine, ReLU, rounding, maxima)
-// is what a second resident block would hide, and 242 VGPRs allow only one.
+// Bound: matrix pipe in fp32 (0.41 ms at peak for B=256: 154/147 of the stem's 60.4 GFLOP), HBM
+// in bf16 (0.3 GB).
 #include <type_traits>
 
 #include "rn_conv_params.h"
@@ -44,8 +49,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kCout = 64, kK = 7;
-constexpr int kPatchRows = 15;  // input rows behind five stem rows: 2*4 + 7
-constexpr int kMaxTiles = 5;    // 32-position M tiles per wave (4 wave rows): Wo <= 128
+constexpr int kPatchRows = 13;  // input rows behind four stem rows: 2*3 + 7
+constexpr int kHaloRows = 7;    // ... behind the one stem row above a segment
+constexpr int kRing = 5;        // pooled rows in LDS: three being written, two leaving
+constexpr int kMaxTiles = 4;    // 4x8 M tiles per wave (4 wave rows): Wo <= 128
 
 struct StemParams {
     const void *in;      // [B][Hp][Wp][CS] physically padded NHWC image (CS = 3 fp32, 4 bf16)
@@ -55,9 +62,8 @@ struct StemParams {
     void *out;           // [B][PH][PW][64]
     int B, Hp, Wp, Ho, Wo, PH, PW;
     int Cin;             // NCHW input only: channels of the image (1..3)
-    int relu;
-    unsigned items;      // B * ceil(PH / 2)
-    int pairs;           // ceil(PH / 2)
+    int pairs;           // items per image: ceil(PH / 2)
+    int seg_len, segs;   // items per block, blocks per image (segs * seg_len >= pairs)
 };
 
 template <typename T>
@@ -90,18 +96,22 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
     constexpr int STEPS = kK * C::STEPS_ROW;    // MFMA k-steps: 77 / 14
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int rowb = p.Wp * PIXB;               // bytes per patch row
-    // LDS: two input patches and two pooled-row buffers (item i is multiplied out of one patch
-    // while the next item's lands in the other and the previous item's pooled rows leave)
+    // LDS: two input patches (item i is multiplied out of one while the next item's lands in the
+    // other) and the ring of pooled rows
     const int patch_bytes = 48 + ((kPatchRows * rowb + 15) & ~15);  // slack: shifted base in front, piece overhang behind
-    const int pooled_n = 2 * p.PW * kCout;                           // floats of one [2][PW][64] buffer
-    float *const pooled0 = reinterpret_cast<float *>(lds + 2 * patch_bytes);
+    const int ring_row = p.PW * kCout;                               // 32-bit words of one pooled row
+    unsigned *const ring = reinterpret_cast<unsigned *>(lds + 2 * patch_bytes);
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int n = wn * 32 + li;  // this lane's output channel
-    const int n2d = p.Wo >> 3, ntiles = n2d + ((p.Wo + 31) >> 5);  // 4x8 tiles of rows 0..3, 1x32 tiles of row 4
+    const int n2d = p.Wo >> 3, n1d = (p.Wo + 31) >> 5;  // 4x8 tiles of an item, 1x32 tiles of a halo row
+    const int b = (int)(blockIdx.x / (unsigned)p.segs);
+    const int pj0 = ((int)blockIdx.x - b * p.segs) * p.seg_len;
+    const int pj1 = min(pj0 + p.seg_len, p.pairs);
+    if (pj0 >= pj1) return;
 
     // weights of this lane's channel: B operand of every k-step, loaded once
     typename std::conditional<sizeof(T) == 4, float, i32x4>::type bw[STEPS];
@@ -118,26 +128,24 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
     const float sc = p.scale ? p.scale[n] : 1.f;
     const float sh = p.shift ? p.shift[n] : 0.f;
 
-    for (int i = t; i < 2 * pooled_n; i += 512) pooled0[i] = 0.f;
+    for (int i = t; i < kRing * ring_row; i += 512) ring[i] = 0u;
     if constexpr (NCHW_IN) {  // the patches' border pixels and pad channel are zero and stay zero
         for (int i = t * 16; i < 2 * patch_bytes; i += 512 * 16)
             *reinterpret_cast<i32x4 *>(lds + i) = i32x4{0, 0, 0, 0};
         __syncthreads();
     }
 
-    // The input patch of an item: rows [row0, row0 + 15) of the padded image clipped to the image --
-    // one contiguous block of memory -- fetched as 16-byte pieces from the 16-byte boundary below
-    // its first byte (fp32 rows are only 8-byte multiples; the LDS image is shifted likewise, it
-    // starts 16 or 24 bytes into the array).  All pieces of a thread are independent loads, issued for
-    // item i+1 before the contraction of item i and written to LDS after it: the fetch hides
-    // behind the matrix work instead of standing in front of it.
-    // 512 threads x 16 B x 6 = 48 KB >= 15 rows of 266 fp32 pixels; NCHW: 6 x 8 waves >= 45 channel rows
+    // An input patch: rows [row0, row0 + nrows) of the padded image clipped to the image -- one
+    // contiguous block of memory -- fetched as 16-byte pieces from the 16-byte boundary below its
+    // first byte (fp32 rows are only 8-byte multiples; the LDS image is shifted likewise, it starts
+    // 16 or 24 bytes into the array).  All pieces of a thread are independent loads, issued for
+    // item i+1 before the contraction of item i and written to LDS in the middle of it: the fetch
+    // hides behind the matrix work instead of standing in front of it.
+    // 512 threads x 16 B x 6 = 48 KB >= 13 rows of 266 fp32 pixels; NCHW: 6 x 8 waves >= 39 channel rows
     constexpr int kPieces = 6;
     i32x4 stage[kPieces];
-    auto patch_src = [&](unsigned item, const char *&src, int &dst_off, int &nbytes, int &base) {
-        const int b = (int)(item / (unsigned)p.pairs), pj = (int)(item % (unsigned)p.pairs);
-        const int row0 = 2 * (4 * pj - 1);
-        const int lo = max(row0, 0), hi = min(row0 + kPatchRows, p.Hp);
+    auto patch_src = [&](int row0, int nrows, const char *&src, int &dst_off, int &nbytes, int &base) {
+        const int lo = max(row0, 0), hi = min(row0 + nrows, p.Hp);
         const char *first = static_cast<const char *>(p.in) + ((size_t)b * p.Hp + lo) * rowb;
         const int mis = (int)(reinterpret_cast<uintptr_t>(first) & 15);
         src = first - mis;
@@ -153,21 +161,20 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
     // of T at pixel stride; rows outside the image are stored as zeros (the buffer held another
     // item's rows).
     const int W4 = (p.Wp - 6) >> 2;
-    auto unit_of = [&](int k, int &r, int &c, int &q) -> bool {
+    auto unit_of = [&](int k, int nrows, int &r, int &c, int &q) -> bool {
         const int rc = (t >> 6) + 8 * k;
         q = t & 63;
         r = p.Cin == 3 ? (rc * 43) >> 7 : p.Cin == 2 ? rc >> 1 : rc;  // rc / Cin for rc < 48
         c = rc - r * p.Cin;
-        return r < kPatchRows && q < W4;
+        return r < nrows && q < W4;
     };
-    auto patch_fetch = [&](unsigned item) {
+    auto patch_fetch = [&](int row0, int nrows) {
         if constexpr (NCHW_IN) {
-            const int b = (int)(item / (unsigned)p.pairs), pj = (int)(item % (unsigned)p.pairs);
-            const int row0 = 2 * (4 * pj - 1), H = p.Hp - 6, W = p.Wp - 6;
+            const int H = p.Hp - 6, W = p.Wp - 6;
 #pragma unroll
             for (int k = 0; k < kPieces; ++k) {
                 int r, c, q;
-                const bool ok = unit_of(k, r, c, q);
+                const bool ok = unit_of(k, nrows, r, c, q);
                 const int ih = row0 + r - 3;
                 const bool real = ok && ih >= 0 && ih < H;
                 const float *src = static_cast<const float *>(p.in) +
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
         } else {
             const char *src;
             int dst_off, nbytes, base;
-            patch_src(item, src, dst_off, nbytes, base);
+            patch_src(row0, nrows, src, dst_off, nbytes, base);
 #pragma unroll
             for (int k = 0; k < kPieces; ++k) {
                 const int o = (k * 512 + t) * 16;
@@ -186,12 +193,12 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
             }
         }
     };
-    auto patch_store = [&](unsigned item, int buf) -> int {
+    auto patch_store = [&](int row0, int nrows, int buf) -> int {
         if constexpr (NCHW_IN) {
 #pragma unroll
             for (int k = 0; k < kPieces; ++k) {
                 int r, c, q;
-                if (!unit_of(k, r, c, q)) continue;
+                if (!unit_of(k, nrows, r, c, q)) continue;
                 T *dst = reinterpret_cast<T *>(lds + buf * patch_bytes + 16 + r * rowb) + (3 + 4 * q) * C::CS + c;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dst[i * C::CS] = (T)__int_as_float(stage[k][i]);
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
         } else {
             const char *src;
             int dst_off, nbytes, base;
-            patch_src(item, src, dst_off, nbytes, base);
+            patch_src(row0, nrows, src, dst_off, nbytes, base);
 #pragma unroll
             for (int k = 0; k < kPieces; ++k) {
                 const int o = (k * 512 + t) * 16;
@@ -209,172 +216,181 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
             return buf * patch_bytes + base;
         }
     };
-    // pooled rows of a finished item -> global, then cleared for the item after next
-    auto pooled_out = [&](unsigned item, float *pooled) {
-        const int b = (int)(item / (unsigned)p.pairs), ph0 = 2 * (int)(item % (unsigned)p.pairs);
-        const int rows = min(2, p.PH - ph0);
-        const int nout = rows * p.PW * kCout;
-        char *obase = static_cast<char *>(p.out) + ((size_t)b * p.PH + ph0) * p.PW * kCout * ES;
-        for (int i = t * 4; i < nout; i += 512 * 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(pooled + i);
-            if constexpr (sizeof(T) == 4) {
-                *reinterpret_cast<float4 *>(obase + (size_t)i * 4) = v;
-            } else {
-                typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
-                bf16x4 o;
-                o[0] = (bf16_t)v.x, o[1] = (bf16_t)v.y, o[2] = (bf16_t)v.z, o[3] = (bf16_t)v.w;
-                *reinterpret_cast<bf16x4 *>(obase + (size_t)i * 2) = o;
+    // the two pooled rows an item completed -> global, their ring slots cleared for the rows that
+    // come round to them (2 * item + 5, + 6: first touched two items later)
+    auto ship = [&](int pj) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const int ph = 2 * pj + pl;
+            if (ph >= p.PH) break;
+            unsigned *src = ring + (ph % kRing) * ring_row;
+            char *obase = static_cast<char *>(p.out) + ((size_t)b * p.PH + ph) * ring_row * ES;
+            for (int i = t * 4; i < ring_row; i += 512 * 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + i);
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4 *>(obase + (size_t)i * 4) = v;
+                } else {
+                    typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 o;
+                    o[0] = (bf16_t)v.x, o[1] = (bf16_t)v.y, o[2] = (bf16_t)v.z, o[3] = (bf16_t)v.w;
+                    *reinterpret_cast<bf16x4 *>(obase + (size_t)i * 2) = o;
+                }
+                *reinterpret_cast<float4 *>(src + i) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            *reinterpret_cast<float4 *>(pooled + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // y = relu(acc * scale + shift) as the bit pattern the integer maxima order by
+    auto finish = [&](float a) -> unsigned {
+        float v = fmaf(a, sc, sh);
+        v = v > 0.f ? v : 0.f;  // never -0.0: the bit pattern must order like the value
+        if constexpr (sizeof(T) == 2) v = (float)(bf16_t)v;
+        return __float_as_uint(v);
+    };
+    // Four adjacent columns 4c .. 4c+3 of one stem row (or the vertical maximum of several) feed
+    // the windows 2c (4c, 4c+1), 2c+1 (4c+1 .. 4c+3) and 2c+2 (4c+3): three LDS maxima into the
+    // ring row `row`.
+    auto put = [&](unsigned *row, int pw, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+        unsigned *q0 = row + pw * kCout + n;
+        atomicMax(q0, max(v0, v1));
+        atomicMax(q0 + kCout, max(max(v1, v2), v3));
+        // past the right edge there is no window 2c+2: v3 goes to window 2c+1 once more (it is
+        // part of that maximum already) instead of a branch around the instruction
+        atomicMax(q0 + (pw + 2 < p.PW ? 2 * kCout : kCout), v3);
+    };
+    // one MFMA chain: the 32 positions `abase` points at x this lane's channel, over K
+    auto mfma_row = [&](f32x16 &acc, const char *patch, int arow, int kh) {
+#pragma unroll
+        for (int q = 0; q < C::STEPS_ROW; ++q) {
+            const int s = kh * C::STEPS_ROW + q;
+            if constexpr (sizeof(T) == 4) {
+                const float a = *reinterpret_cast<const float *>(patch + arow + q * C::KPS * ES);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s], acc, 0, 0, 0);
+            } else {
+                const i32x4 a = *reinterpret_cast<const i32x4 *>(patch + arow + q * C::KPS * ES);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                             __builtin_bit_cast(bf16x8, bw[s]), acc, 0, 0, 0);
+            }
         }
     };
 
-    // Software pipeline over the block's items, ONE barrier per item: while item i is multiplied
-    // out of patch[i&1], the patch of item i+1 is written to the other buffer (fetched to
-    // registers during item i-1), the fetch of item i+2 is issued, and the pooled rows of item
-    // i-1 leave from pooled[(i-1)&1].  All of that sits in the middle of item i's k loop, between
-    // MFMAs; only the epilogue of an item is not covered by matrix work.
-    const unsigned step = gridDim.x;
-    if (blockIdx.x >= p.items) return;
-    patch_fetch(blockIdx.x);
-    int patch_off = patch_store(blockIdx.x, 0);
-    if (blockIdx.x + step < p.items) patch_fetch(blockIdx.x + step);
+    // ---- start-up: the first item's patch, the halo row's if the segment starts inside the image
+    patch_fetch(8 * pj0, kPatchRows);
+    int patch_off = patch_store(8 * pj0, kPatchRows, 0);
+    int halo_off = 0;
+    if (pj0 > 0) {
+        patch_fetch(8 * pj0 - 2, kHaloRows);
+        halo_off = patch_store(8 * pj0 - 2, kHaloRows, 1);
+    }
+    if (pj0 + 1 < pj1) patch_fetch(8 * (pj0 + 1), kPatchRows);
     __syncthreads();
-    int cur = 0;
-    for (unsigned item = blockIdx.x; item < p.items; item += step, cur ^= 1) {
-        const int pj = (int)(item % (unsigned)p.pairs);
-        const int ph0 = 2 * pj;
-        const int oh_first = 2 * ph0 - 1;     // stem row of r = 0 (-1 for the first pair: no such row)
-        const char *const patch = lds + patch_off;  // patch row 0 of this item
-        float *const pooled = pooled0 + cur * pooled_n;
-        int next_off = 0;
+    if (pj0 > 0) {
+        // stem row 4*pj0 - 1, the top row of pooled row 2*pj0's windows: 1x32 tiles, one per wave row
+        if (wm < n1d) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            const int ox = 32 * wm + li;
+            const int abase = ox < p.Wo ? 2 * ox * PIXB + lh * (C::KPS / 2) * ES : 0;
+#pragma unroll
+            for (int kh = 0; kh < kK; ++kh) mfma_row(acc, lds + halo_off, abase + kh * rowb, kh);
+            unsigned *row = ring + ((2 * pj0) % kRing) * ring_row;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int oxg = 32 * wm + 8 * g + 4 * lh;
+                if (oxg >= p.Wo) continue;
+                put(row, oxg >> 1, finish(acc[4 * g]), finish(acc[4 * g + 1]), finish(acc[4 * g + 2]),
+                    finish(acc[4 * g + 3]));
+            }
+        }
+        __syncthreads();  // the second patch buffer is free for item pj0 + 1
+    }
 
+    // ---- the items, ONE barrier each: while item i is multiplied out of patch[i&1], the patch of
+    // item i+1 is written to the other buffer (fetched to registers during item i-1), the fetch of
+    // item i+2 is issued and the pooled rows item i-1 completed leave -- all of that in the middle
+    // of the first tile's MFMA chain.
+    const int ntw = wm < n2d ? (n2d - wm + 3) >> 2 : 0;  // this wave's tiles: wm, wm+4, ...
+    int cur = 0;
+    for (int pj = pj0; pj < pj1; ++pj, cur ^= 1) {
+        const char *const patch = lds + patch_off;  // patch row 0 of this item = padded image row 8*pj
+        int next_off = 0;
         // Per-item copies of the lane / wave coordinates that the compiler cannot see through:
         // everything below depends only on them and on the kernel arguments, and hoisted out of
-        // the item loop (385 fragment addresses, the epilogue's index arithmetic) it costs more
-        // than a thousand spilled registers.
+        // the item loop (the fragment addresses, the epilogue's index arithmetic) it would cost
+        // hundreds of registers.
         int li_ = li, lh_ = lh, wm_ = wm;
         asm volatile("" : "+v"(li_), "+v"(lh_), "+s"(wm_));
+        // ring rows of pooled rows 2pj, 2pj+1 (completed by this item) and 2pj+2 (its top row only)
+        unsigned *const row0 = ring + ((2 * pj) % kRing) * ring_row;
+        unsigned *const row1 = ring + ((2 * pj + 1) % kRing) * ring_row;
+        unsigned *const row2 = ring + ((2 * pj + 2) % kRing) * ring_row;
+        // (a pooled row at or past PH -- the last item of an image -- takes its maxima like any
+        // other: its ring row is never shipped and the block ends with that item)
+        const int oh0 = 4 * pj;  // stem row of tile row 0; rows at or below Ho do not exist and count as 0
 
-        // ---- contraction: wave (wm, wn) owns M tiles wm, wm+4, ... and channels 32*wn ..
-        // M tiles: n2d tiles of 4 stem rows (r = 0..3) x 8 columns -- lane li is (row li>>3, column
-        // li&7) -- then n1d tiles of 32 columns of stem row r = 4.  In the accumulator of a 4x8
-        // tile a lane then holds, for its channel, rows 0..3 of four adjacent columns (element e:
-        // row e>>2, column 4*lh + (e&3)): the vertical part of the pool happens in registers.
-        f32x16 acc[kMaxTiles];
-        int abase[kMaxTiles];
+        auto duties = [&]() {  // the other buffers' turn; their last users are a barrier behind
+            if (pj + 1 < pj1) {
+                next_off = patch_store(8 * (pj + 1), kPatchRows, cur ^ 1);
+                if (pj + 2 < pj1) patch_fetch(8 * (pj + 2), kPatchRows);
+            }
+            if (pj > pj0) ship(pj - 1);
+        };
+        // M tile `tile`: lane li is (stem row li>>3, column 8*tile + (li&7)); in the accumulator a
+        // lane then holds, for its channel, rows 0..3 of four adjacent columns (element e: row e>>2,
+        // column 4*lh + (e&3)): the vertical part of the pool happens in registers.
+        auto abase_of = [&](int tile) {
+            return 2 * (li_ >> 3) * rowb + 2 * (8 * tile + (li_ & 7)) * PIXB + lh_ * (C::KPS / 2) * ES;
+        };
+        auto epilogue = [&](const f32x16 &acc, int tile) {
+            const int pw = 4 * tile + 2 * lh_;  // (8*tile + 4*lh) / 2
+            unsigned y[4][4];
 #pragma unroll
-        for (int j = 0; j < kMaxTiles; ++j) {
+            for (int dr = 0; dr < 4; ++dr) {
+                const bool real = oh0 + dr < p.Ho;  // wave-uniform
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-            const int tile = wm_ + 4 * j;
-            const bool two_d = tile < n2d;
-            const int r = two_d ? li_ >> 3 : 4;
-            const int ox = two_d ? 8 * tile + (li_ & 7) : 32 * (tile - n2d) + li_;
-            // patch row 2r + kh, pixel 2*ox + kw; the lane half takes the upper half of a k-step
-            abase[j] = ox < p.Wo ? 2 * r * rowb + 2 * ox * PIXB + lh_ * (C::KPS / 2) * ES : 0;
-        }
-        // NT = tiles this wave multiplies (a compile-time count: a per-tile "does it exist" test
-        // inside the k loop puts a branch around every MFMA and serialises read -> wait -> MFMA)
-        auto contract = [&](auto nt_c) {
-            constexpr int NT = decltype(nt_c)::value;
+                for (int i = 0; i < 4; ++i) y[dr][i] = real ? finish(acc[4 * dr + i]) : 0u;
+            }
+            // windows of pooled row 2pj: stem rows (4pj-1), 4pj, 4pj+1; of row 2pj+1: 4pj+1 .. 4pj+3;
+            // of row 2pj+2: 4pj+3 (and the next item's first two)
+            put(row0, pw, max(y[0][0], y[1][0]), max(y[0][1], y[1][1]), max(y[0][2], y[1][2]), max(y[0][3], y[1][3]));
+            put(row1, pw, max(max(y[1][0], y[2][0]), y[3][0]), max(max(y[1][1], y[2][1]), y[3][1]),
+                max(max(y[1][2], y[2][2]), y[3][2]), max(max(y[1][3], y[2][3]), y[3][3]));
+            put(row2, pw, y[3][0], y[3][1], y[3][2], y[3][3]);
+        };
+
+        if (ntw == 0) {
+            duties();
+        } else {
+            // first tile: the chain carries the block's housekeeping
+            f32x16 acc;
 #pragma unroll
-            for (int kh = 0; kh < kK; ++kh) {
-                if (kh == 3) {  // the other buffers' turn (see above); their last users are a barrier behind
-                    if (item + step < p.items) {
-                        next_off = patch_store(item + step, cur ^ 1);
-                        if (item + 2 * step < p.items) patch_fetch(item + 2 * step);
-                    }
-                    if (item != blockIdx.x) pooled_out(item - step, pooled0 + (cur ^ 1) * pooled_n);
-                }
-                int arow[NT];  // this kernel row's fragment base; the k-steps are immediates
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            {
+                const int ab = abase_of(wm_);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) arow[j] = abase[j] + kh * rowb;
-#pragma unroll
-                for (int q = 0; q < C::STEPS_ROW; ++q) {
-                    const int s = kh * C::STEPS_ROW + q;
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        if constexpr (sizeof(T) == 4) {
-                            const float a = *reinterpret_cast<const float *>(patch + arow[j] + q * C::KPS * ES);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s], acc[j], 0, 0, 0);
-                        } else {
-                            const i32x4 a = *reinterpret_cast<const i32x4 *>(patch + arow[j] + q * C::KPS * ES);
-                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, bw[s]), acc[j], 0, 0, 0);
-                        }
-                    }
+                for (int kh = 0; kh < kK; ++kh) {
+                    if (kh == 3) duties();
+                    mfma_row(acc, patch, ab + kh * rowb, kh);
                 }
             }
-        };
-        // tiles wm, wm+4, ... < ntiles: five for the widest images' first wave rows, else four or
-        // fewer (a tile that does not exist is multiplied on patch garbage and never looked at)
-        if (wm_ + 4 * (kMaxTiles - 1) < ntiles)
-            contract(std::integral_constant<int, kMaxTiles>{});
-        else
-            contract(std::integral_constant<int, kMaxTiles - 1>{});
-
-        // ---- epilogue: affine, ReLU, max into the pooled rows.  y >= 0 everywhere, so a stem row
-        // that does not exist (above the image for the first pair, below it for the last) counts
-        // as 0, the value the pooled rows start from.  Four adjacent columns 4c .. 4c+3 feed the
-        // windows 2c (4c, 4c+1), 2c+1 (4c+1 .. 4c+3) and 2c+2 (4c+3): three LDS maxima.
-        auto finish = [&](float a) -> unsigned {
-            float v = fmaf(a, sc, sh);
-            if (p.relu) v = v > 0.f ? v : 0.f;  // never -0.0: the bit pattern must order like the value
-            if constexpr (sizeof(T) == 2) v = (float)(bf16_t)v;
-            return __float_as_uint(v);
-        };
-        auto put = [&](int pl, int pw, const unsigned (&v)[4]) {
-            if (ph0 + pl >= p.PH) return;
-            unsigned *q0 = reinterpret_cast<unsigned *>(pooled) + ((pl * p.PW + pw) * kCout + n);
-            atomicMax(q0, max(v[0], v[1]));
-            atomicMax(q0 + kCout, max(max(v[1], v[2]), v[3]));
-            if (pw + 2 < p.PW) atomicMax(q0 + 2 * kCout, v[3]);
-        };
+            // tiles 1 ..: the chain of tile j carries the epilogue of tile j-1
+            for (int j = 1; j < ntw; ++j) {
+                const f32x16 prev = acc;
+                const int tile = wm_ + 4 * j;
+                const int ab = abase_of(tile);
 #pragma unroll
-        for (int j = 0; j < kMaxTiles; ++j) {
-            const int tile = wm_ + 4 * j;
-            if (tile >= ntiles) continue;
-            if (tile < n2d) {
-                const int pw = 4 * tile + 2 * lh_;  // (8*tile + 4*lh) / 2
-                unsigned y[4][4];
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                mfma_row(acc, patch, ab, 0);
+                epilogue(prev, tile - 4);
 #pragma unroll
-                for (int dr = 0; dr < 4; ++dr) {
-                    const int oh = oh_first + dr;
-                    const bool real = oh >= 0 && oh < p.Ho;  // wave-uniform
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) y[dr][i] = real ? finish(acc[j][4 * dr + i]) : 0u;
-                }
-                unsigned v0[4], v1[4];  // windows of pooled row 0: stem rows 0..2; of row 1: 2..4
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v0[i] = max(max(y[0][i], y[1][i]), y[2][i]);
-                    v1[i] = max(y[2][i], y[3][i]);
-                }
-                put(0, pw, v0);
-                put(1, pw, v1);
-            } else {
-                const int oh = oh_first + 4;
-                if (oh >= p.Ho) continue;  // wave-uniform
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ox = 32 * (tile - n2d) + 8 * g + 4 * lh_;
-                    if (ox >= p.Wo) continue;
-                    unsigned v[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = finish(acc[j][4 * g + i]);
-                    put(1, ox >> 1, v);
-                }
+                for (int kh = 1; kh < kK; ++kh) mfma_row(acc, patch, ab + kh * rowb, kh);
             }
+            epilogue(acc, wm_ + 4 * (ntw - 1));
         }
         __syncthreads();
         patch_off = next_off;
     }
-    // the last item's pooled rows (cur was flipped once more by the loop)
-    {
-        const unsigned n_mine = (p.items - 1 - blockIdx.x) / step;  // index of this block's last item
-        pooled_out(blockIdx.x + n_mine * step, pooled0 + (cur ^ 1) * pooled_n);
-    }
+    ship(pj1 - 1);  // the last item's pooled rows
 }
 
 // OIHW fp32 [64][3][7][7] -> the panel the kernel keeps in registers
@@ -439,7 +455,7 @@ static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, 
     RN_REQUIRE(ctx, Hp >= 7 && Wp >= 7 && Hp < (1u << 14) && Wp < (1u << 14), "image size out of range");
     const uint64_t Ho = rn_conv_output_size(Hp, 7, 2, 0), Wo = rn_conv_output_size(Wp, 7, 2, 0);
     const uint64_t PH = rn_conv_output_size(Ho, 3, 2, 1), PW = rn_conv_output_size(Wo, 3, 2, 1);
-    RN_REQUIRE(ctx, Wo / 8 + (Wo + 31) / 32 <= 4 * kMaxTiles, "image too wide for the fused stem (conv output width <= 128)");
+    RN_REQUIRE(ctx, Wo / 8 <= 4 * kMaxTiles, "image too wide for the fused stem (conv output width <= 128)");
     RN_REQUIRE(ctx, Wo % 8 == 0, "the fused stem needs a conv output width that is a multiple of 8");
     const int es = dtype == RN_DTYPE_BF16 ? 2 : 4, cs = dtype == RN_DTYPE_BF16 ? 4 : 3;
     RN_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out) |
@@ -469,15 +485,28 @@ static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, 
     p.PH = (int)PH;
     p.PW = (int)PW;
     p.Cin = (int)Cin;
-    p.relu = relu;
     p.pairs = (int)rn_ceil_div(PH, 2);
-    p.items = (unsigned)(B * (uint64_t)p.pairs);
+    // A block walks seg_len items of one image; a segment that starts inside an image computes one
+    // stem row more (the halo tile).  One block per CU (LDS): the launch takes ceil(blocks / CUs)
+    // rounds of the longest block, so pick the segment length that minimises rounds x rows per block.
+    {
+        const int cus = ctx->cus;
+        uint64_t best = ~0ull;
+        p.seg_len = 1;
+        for (int len = p.pairs; len >= 1; --len) {
+            const uint64_t segs = rn_ceil_div((uint64_t)p.pairs, (uint64_t)len);
+            const uint64_t rounds = rn_ceil_div(B * segs, (uint64_t)cus);
+            const uint64_t cost = rounds * (4ull * (uint64_t)len + (segs > 1 ? 1 : 0) + 1);  // + start-up
+            if (cost < best) best = cost, p.seg_len = len;
+        }
+        p.segs = (int)rn_ceil_div((uint64_t)p.pairs, (uint64_t)p.seg_len);
+    }
     const size_t patch = 48 + (((size_t)kPatchRows * Wp * cs * es + 15) & ~(size_t)15);
     RN_REQUIRE(ctx, patch <= 48 * 1024, "image too wide for the fused stem (patch)");
-    const size_t lds_bytes = 2 * patch + (size_t)2 * 2 * PW * kCout * sizeof(float);
+    const size_t lds_bytes = 2 * patch + (size_t)kRing * PW * kCout * sizeof(float);
     RN_REQUIRE(ctx, lds_bytes <= 160 * 1024, "image too wide for the fused stem (LDS)");
-    unsigned grid = 256u;  // one block per CU (registers): persistent, items grid-stride
-    if (grid > p.items) grid = p.items;
+    RN_REQUIRE(ctx, B * (uint64_t)p.segs < (1ull << 31), "too many blocks");
+    const unsigned grid = (unsigned)(B * (uint64_t)p.segs);
     const bool bf = dtype == RN_DTYPE_BF16;
     const void *fn = bf ? (nchw ? (const void *)stem_pool_kernel<bf16_t, true> : (const void *)stem_pool_kernel<bf16_t, false>)
                         : (nchw ? (const void *)stem_pool_kernel<float, true> : (const void *)stem_pool_kernel<float, false>);
