@@ -40,6 +40,7 @@
 #include <type_traits>
 
 #include "rn_conv_params.h"
+#include "rn_lds_dma.h"
 
 using namespace rn_gemm;
 
@@ -64,6 +65,11 @@ struct StemParams {
     int Cin;             // NCHW input only: channels of the image (1..3)
     int pairs;           // items per image: ceil(PH / 2)
     int seg_len, segs;   // items per block, blocks per image (segs * seg_len >= pairs)
+    int lrow;            // bytes between patch rows in LDS (>= Wp * pixel bytes)
+    unsigned ppr_mul, ppr_shr;  // bf16: piece / (16-byte pieces per image row) as a multiply-high
+    // diagnostic only (tools/stem_stamps.py): 16 shader-clock stamps per wave of the block's
+    // fourth item, or null
+    unsigned long long *stamps;
 };
 
 template <typename T>
@@ -95,10 +101,17 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
     constexpr int PIXB = C::CS * ES;            // bytes per pixel: 12 / 8
     constexpr int STEPS = kK * C::STEPS_ROW;    // MFMA k-steps: 77 / 14
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int rowb = p.Wp * PIXB;               // bytes per patch row
+    const int rowb = p.Wp * PIXB;               // bytes per image row in memory
+    // Pitch of a patch row in LDS.  bf16: a stem row is two patch rows, and the four stem rows of
+    // an M tile are read by one ds_read_b128 -- 16 lanes a cycle, 8 of them 128 consecutive bytes
+    // of one row, the other 8 of another: conflict-free when two rows are 128 bytes apart
+    // modulo 256, i.e. pitch = 64 (mod 128).  Image rows of 230 pixels are 48 (mod 128): PMC showed
+    // 54 % of the kernel's LDS cycles as bank conflicts.  fp32 rows are copied as one flat block
+    // (they are not 16-byte multiples) and keep the memory pitch.
+    const int lrow = p.lrow;
     // LDS: two input patches (item i is multiplied out of one while the next item's lands in the
     // other) and the ring of pooled rows
-    const int patch_bytes = 48 + ((kPatchRows * rowb + 15) & ~15);  // slack: shifted base in front, piece overhang behind
+    const int patch_bytes = 48 + ((kPatchRows * lrow + 15) & ~15);  // slack: shifted base in front, piece overhang behind
     const int ring_row = p.PW * kCout;                               // 32-bit words of one pooled row
     unsigned *const ring = reinterpret_cast<unsigned *>(lds + 2 * patch_bytes);
 
@@ -135,31 +148,62 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
         __syncthreads();
     }
 
-    // An input patch: rows [row0, row0 + nrows) of the padded image clipped to the image -- one
-    // contiguous block of memory -- fetched as 16-byte pieces from the 16-byte boundary below its
-    // first byte (fp32 rows are only 8-byte multiples; the LDS image is shifted likewise, it starts
-    // 16 or 24 bytes into the array).  All pieces of a thread are independent loads, issued for
-    // item i+1 before the contraction of item i and written to LDS in the middle of it: the fetch
-    // hides behind the matrix work instead of standing in front of it.
-    // 512 threads x 16 B x 6 = 48 KB >= 13 rows of 266 fp32 pixels; NCHW: 6 x 8 waves >= 39 channel rows
-    constexpr int kPieces = 6;
-    i32x4 stage[kPieces];
-    auto patch_src = [&](int row0, int nrows, const char *&src, int &dst_off, int &nbytes, int &base) {
-        const int lo = max(row0, 0), hi = min(row0 + nrows, p.Hp);
-        const char *first = static_cast<const char *>(p.in) + ((size_t)b * p.Hp + lo) * rowb;
-        const int mis = (int)(reinterpret_cast<uintptr_t>(first) & 15);
-        src = first - mis;
-        // LDS offset of patch row 0: 16 or 24, whichever puts the first fetched piece on a
-        // 16-byte boundary
-        base = 16 + ((mis - (lo - row0) * rowb) & 15);
-        dst_off = base + (lo - row0) * rowb - mis;
-        nbytes = (hi - lo) * rowb + mis;
+    // An input patch: rows [row0, row0 + nrows) of the padded image (row0 >= 0; rows past the image
+    // read as zeros), one contiguous block of memory.
+    //
+    // Padded NHWC image (the default): LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction)
+    // straight into the patch buffer the NEXT item reads, issued at the top of an item and waited
+    // for (vmcnt) in front of the barrier that ends it: no staging registers, no ds_write (the
+    // round-2 kernel's register-staged copy cost a wave ~1,400 cycles an item in bf16, with the
+    // matrix pipe idle: stamps).  fp32 rows are not 16-byte multiples: the block is copied flat,
+    // from the 16-byte boundary below its first byte to LDS offset 16 (patch row 0 then starts
+    // 16 + mis bytes in).  bf16 rows land at the padded pitch `lrow`: lane l of piece q fills LDS
+    // bytes [16 (64 q + l), + 16) and fetches the image bytes that belong there (pad bytes: an
+    // out-of-range offset, which lands as zeros).
+    const i32x4 srd = rn_dma::make_srd(static_cast<const char *>(p.in) + (size_t)b * p.Hp * rowb, p.Hp * rowb);
+    const unsigned lds_base = (unsigned)(uintptr_t)((rn_dma::lds_void *)lds);
+    // piece k of the calling wave (wave-instruction q = wave + 8 k of the copy); k = 0 .. kDmaPieces-1
+    // covers 13 rows of up to 266 pixels.  Returns the byte offset of patch row 0 in lds[].
+    constexpr int kDmaPieces = 6;
+    auto patch_dma_piece = [&](int row0, int nrows, int buf, int k) -> int {
+        const int rel = buf * patch_bytes + 16;  // byte offset of the copy's first piece in lds[]
+        const unsigned lds0 = lds_base + (unsigned)rel;
+        const int q = wave + 8 * k;
+        if constexpr (sizeof(T) == 4) {
+            const int g0 = row0 * rowb;
+            const int mis = (int)((reinterpret_cast<uintptr_t>(p.in) + (size_t)b * p.Hp * rowb + (size_t)g0) & 15);
+            const int nbytes = nrows * rowb + mis;
+            // lanes past the block's last byte stay out (EXEC): what lies behind the patch in LDS
+            // -- the other patch, the ring -- is in use
+            if (lane * 16 + q * 1024 < nbytes)
+                rn_dma::dma16(lane * 16 + q * 1024 + g0 - mis, srd, 0,
+                              (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)q * 1024u)));
+            return rel + mis;
+        } else {
+            const int nbytes = nrows * lrow, ppr = rowb >> 4;
+            const unsigned pi = (unsigned)(q * 64 + lane);
+            const int r = (int)(__umulhi(pi, p.ppr_mul) >> p.ppr_shr), c16 = (int)pi - r * (lrow >> 4);
+            const int off = (r < nrows && c16 < ppr) ? (row0 + r) * rowb + c16 * 16 : rn_dma::kOob;
+            if ((int)pi * 16 < nbytes)  // see above
+                rn_dma::dma16(off, srd, 0, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)q * 1024u)));
+            return rel;
+        }
     };
-    // NCHW_IN: a wave fetches one channel row of the patch per piece -- lane q its pixels 4q..4q+3
-    // (one 16-byte load; lanes past W/4 idle) -- piece k of wave w the row-channel rc = w + 8k =
-    // (patch row r) * Cin + c, i.e. channel c of image row row0 + r - 3.  Stored as four elements
-    // of T at pixel stride; rows outside the image are stored as zeros (the buffer held another
-    // item's rows).
+    auto patch_dma = [&](int row0, int nrows, int buf) -> int {
+        int off = 0;
+#pragma unroll
+        for (int k = 0; k < kDmaPieces; ++k) off = patch_dma_piece(row0, nrows, buf, k);
+        return off;
+    };
+    auto dma_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // NCHW_IN: the patch is assembled through registers.  A wave fetches one channel row of the
+    // patch per piece -- lane q its pixels 4q..4q+3 (one 16-byte load; lanes past W/4 idle) --
+    // piece k of wave w the row-channel rc = w + 8k = (patch row r) * Cin + c, i.e. channel c of
+    // image row row0 + r - 3; the loads are issued for item i+1 during item i-1 and stored, as
+    // four elements of T at pixel stride, in the middle of item i.  Rows outside the image are
+    // stored as zeros (the buffer held another item's rows).  6 x 8 waves >= 39 channel rows.
+    constexpr int kPieces = NCHW_IN ? 6 : 1;
+    i32x4 stage[kPieces];
     const int W4 = (p.Wp - 6) >> 2;
     auto unit_of = [&](int k, int nrows, int &r, int &c, int &q) -> bool {
         const int rc = (t >> 6) + 8 * k;
@@ -182,68 +226,49 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
                 const i32x4 v = *reinterpret_cast<const i32x4 *>(src);
                 stage[k] = real ? v : i32x4{0, 0, 0, 0};
             }
-        } else {
-            const char *src;
-            int dst_off, nbytes, base;
-            patch_src(row0, nrows, src, dst_off, nbytes, base);
-#pragma unroll
-            for (int k = 0; k < kPieces; ++k) {
-                const int o = (k * 512 + t) * 16;
-                stage[k] = *reinterpret_cast<const i32x4 *>(src + (o < nbytes ? o : 0));
-            }
         }
     };
-    auto patch_store = [&](int row0, int nrows, int buf) -> int {
+    auto patch_store = [&](int nrows, int buf) -> int {
         if constexpr (NCHW_IN) {
 #pragma unroll
             for (int k = 0; k < kPieces; ++k) {
                 int r, c, q;
                 if (!unit_of(k, nrows, r, c, q)) continue;
-                T *dst = reinterpret_cast<T *>(lds + buf * patch_bytes + 16 + r * rowb) + (3 + 4 * q) * C::CS + c;
+                T *dst = reinterpret_cast<T *>(lds + buf * patch_bytes + 16 + r * lrow) + (3 + 4 * q) * C::CS + c;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dst[i * C::CS] = (T)__int_as_float(stage[k][i]);
             }
-            return buf * patch_bytes + 16;
-        } else {
-            const char *src;
-            int dst_off, nbytes, base;
-            patch_src(row0, nrows, src, dst_off, nbytes, base);
-#pragma unroll
-            for (int k = 0; k < kPieces; ++k) {
-                const int o = (k * 512 + t) * 16;
-                if (o < nbytes) *reinterpret_cast<i32x4 *>(lds + buf * patch_bytes + dst_off + o) = stage[k];
+        }
+        return buf * patch_bytes + 16;
+    };
+    // The two pooled rows an item completed -> global, their ring slots cleared for the rows that
+    // come round to them (2 * item + 5, + 6: first touched two items later).  Waves 0-3 take the
+    // first row, waves 4-7 the second, each at a point of its own choosing inside the next item:
+    // the two waves of a SIMD (w and w + 4) then never do this at the same time, and the one keeps
+    // the matrix pipe busy while the other moves bytes.
+    auto ship_row = [&](int ph) {
+        if (ph >= p.PH) return;
+        unsigned *src = ring + (ph % kRing) * ring_row;
+        char *obase = static_cast<char *>(p.out) + ((size_t)b * p.PH + ph) * ring_row * ES;
+        for (int i = (t & 255) * 4; i < ring_row; i += 256 * 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + i);
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<float4 *>(obase + (size_t)i * 4) = v;
+            } else {
+                typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 o;
+                o[0] = (bf16_t)v.x, o[1] = (bf16_t)v.y, o[2] = (bf16_t)v.z, o[3] = (bf16_t)v.w;
+                *reinterpret_cast<bf16x4 *>(obase + (size_t)i * 2) = o;
             }
-            return buf * patch_bytes + base;
+            *reinterpret_cast<float4 *>(src + i) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    // the two pooled rows an item completed -> global, their ring slots cleared for the rows that
-    // come round to them (2 * item + 5, + 6: first touched two items later)
-    auto ship = [&](int pj) {
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-            const int ph = 2 * pj + pl;
-            if (ph >= p.PH) break;
-            unsigned *src = ring + (ph % kRing) * ring_row;
-            char *obase = static_cast<char *>(p.out) + ((size_t)b * p.PH + ph) * ring_row * ES;
-            for (int i = t * 4; i < ring_row; i += 512 * 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(src + i);
-                if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<float4 *>(obase + (size_t)i * 4) = v;
-                } else {
-                    typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
-                    bf16x4 o;
-                    o[0] = (bf16_t)v.x, o[1] = (bf16_t)v.y, o[2] = (bf16_t)v.z, o[3] = (bf16_t)v.w;
-                    *reinterpret_cast<bf16x4 *>(obase + (size_t)i * 2) = o;
-                }
-                *reinterpret_cast<float4 *>(src + i) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    // y = relu(acc * scale + shift) as the bit pattern the integer maxima order by
+    // y = relu(acc * scale + shift) as the bit pattern the integer maxima order by.  bf16: the
+    // unfused path rounds the stem output before the pool; rounding is monotone, so the maximum of
+    // the rounded values is the rounded maximum -- the ring keeps fp32 and ship() rounds once.
     auto finish = [&](float a) -> unsigned {
         float v = fmaf(a, sc, sh);
         v = v > 0.f ? v : 0.f;  // never -0.0: the bit pattern must order like the value
-        if constexpr (sizeof(T) == 2) v = (float)(bf16_t)v;
         return __float_as_uint(v);
     };
     // Four adjacent columns 4c .. 4c+3 of one stem row (or the vertical maximum of several) feed
@@ -257,42 +282,59 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
         // part of that maximum already) instead of a branch around the instruction
         atomicMax(q0 + (pw + 2 < p.PW ? 2 * kCout : kCout), v3);
     };
-    // one MFMA chain: the 32 positions `abase` points at x this lane's channel, over K
+    // one kernel row of an MFMA chain: the 32 positions `arow` points at x this lane's channel.
+    // The chain's first step starts from a constant zero (an inline operand of the instruction,
+    // not sixteen registers to clear).
     auto mfma_row = [&](f32x16 &acc, const char *patch, int arow, int kh) {
 #pragma unroll
         for (int q = 0; q < C::STEPS_ROW; ++q) {
             const int s = kh * C::STEPS_ROW + q;
+            f32x16 c = acc;
+            if (kh == 0 && q == 0) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) c[e] = 0.f;
+            }
             if constexpr (sizeof(T) == 4) {
                 const float a = *reinterpret_cast<const float *>(patch + arow + q * C::KPS * ES);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[s], c, 0, 0, 0);
             } else {
                 const i32x4 a = *reinterpret_cast<const i32x4 *>(patch + arow + q * C::KPS * ES);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                             __builtin_bit_cast(bf16x8, bw[s]), acc, 0, 0, 0);
+                                                             __builtin_bit_cast(bf16x8, bw[s]), c, 0, 0, 0);
             }
         }
     };
 
+    // diagnostic stamps of one steady-state item (the fourth of the block), every wave for itself
+    auto stamp = [&](int pj, int slot) {
+        if (p.stamps && pj == pj0 + 3 && lane == 0)
+            p.stamps[((size_t)blockIdx.x * 8 + wave) * 16 + slot] = __builtin_amdgcn_s_memtime();
+    };
+
     // ---- start-up: the first item's patch, the halo row's if the segment starts inside the image
-    patch_fetch(8 * pj0, kPatchRows);
-    int patch_off = patch_store(8 * pj0, kPatchRows, 0);
-    int halo_off = 0;
-    if (pj0 > 0) {
-        patch_fetch(8 * pj0 - 2, kHaloRows);
-        halo_off = patch_store(8 * pj0 - 2, kHaloRows, 1);
+    int patch_off, halo_off = 0;
+    if constexpr (NCHW_IN) {
+        patch_fetch(8 * pj0, kPatchRows);
+        patch_off = patch_store(kPatchRows, 0);
+        if (pj0 > 0) {
+            patch_fetch(8 * pj0 - 2, kHaloRows);
+            halo_off = patch_store(kHaloRows, 1);
+        }
+        if (pj0 + 1 < pj1) patch_fetch(8 * (pj0 + 1), kPatchRows);
+    } else {
+        patch_off = patch_dma(8 * pj0, kPatchRows, 0);
+        if (pj0 > 0) halo_off = patch_dma(8 * pj0 - 2, kHaloRows, 1);
+        dma_landed();
     }
-    if (pj0 + 1 < pj1) patch_fetch(8 * (pj0 + 1), kPatchRows);
     __syncthreads();
     if (pj0 > 0) {
         // stem row 4*pj0 - 1, the top row of pooled row 2*pj0's windows: 1x32 tiles, one per wave row
         if (wm < n1d) {
             f32x16 acc;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
             const int ox = 32 * wm + li;
             const int abase = ox < p.Wo ? 2 * ox * PIXB + lh * (C::KPS / 2) * ES : 0;
 #pragma unroll
-            for (int kh = 0; kh < kK; ++kh) mfma_row(acc, lds + halo_off, abase + kh * rowb, kh);
+            for (int kh = 0; kh < kK; ++kh) mfma_row(acc, lds + halo_off, abase + kh * lrow, kh);
             unsigned *row = ring + ((2 * pj0) % kRing) * ring_row;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -306,10 +348,10 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
     }
 
     // ---- the items, ONE barrier each: while item i is multiplied out of patch[i&1], the patch of
-    // item i+1 is written to the other buffer (fetched to registers during item i-1), the fetch of
-    // item i+2 is issued and the pooled rows item i-1 completed leave -- all of that in the middle
-    // of the first tile's MFMA chain.
+    // item i+1 lands in the other buffer and the pooled rows item i-1 completed leave.
     const int ntw = wm < n2d ? (n2d - wm + 3) >> 2 : 0;  // this wave's tiles: wm, wm+4, ...
+    // the tile in whose chain this wave ships its pooled row: the two waves of a SIMD differ
+    const int ship_tile = (wave >= 4 && ntw > 1) ? 1 : 0;
     int cur = 0;
     for (int pj = pj0; pj < pj1; ++pj, cur ^= 1) {
         const char *const patch = lds + patch_off;  // patch row 0 of this item = padded image row 8*pj
@@ -328,18 +370,32 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
         // other: its ring row is never shipped and the block ends with that item)
         const int oh0 = 4 * pj;  // stem row of tile row 0; rows at or below Ho do not exist and count as 0
 
-        auto duties = [&]() {  // the other buffers' turn; their last users are a barrier behind
-            if (pj + 1 < pj1) {
-                next_off = patch_store(8 * (pj + 1), kPatchRows, cur ^ 1);
-                if (pj + 2 < pj1) patch_fetch(8 * (pj + 2), kPatchRows);
+        stamp(pj, 0);
+        // the next item's patch (the other buffer's last readers are a barrier behind).  Measured:
+        // the pieces spread over the kernel rows of one tile's chain instead of issued here, 107 ->
+        // 110 us in bf16 -- the wave pays for their issue wherever they stand.
+        if constexpr (!NCHW_IN) {
+            if (pj + 1 < pj1) next_off = patch_dma(8 * (pj + 1), kPatchRows, cur ^ 1);
+        }
+        stamp(pj, 1);
+        auto staged_patch = [&]() {  // NCHW_IN: registers -> the other buffer, next fetch issued
+            if constexpr (NCHW_IN) {
+                if (pj + 1 < pj1) {
+                    next_off = patch_store(kPatchRows, cur ^ 1);
+                    if (pj + 2 < pj1) patch_fetch(8 * (pj + 2), kPatchRows);
+                }
             }
-            if (pj > pj0) ship(pj - 1);
+        };
+        auto ship_mine = [&]() {
+            stamp(pj, 3);
+            if (pj > pj0) ship_row(2 * (pj - 1) + (wave >> 2));
+            stamp(pj, 4);
         };
         // M tile `tile`: lane li is (stem row li>>3, column 8*tile + (li&7)); in the accumulator a
         // lane then holds, for its channel, rows 0..3 of four adjacent columns (element e: row e>>2,
         // column 4*lh + (e&3)): the vertical part of the pool happens in registers.
         auto abase_of = [&](int tile) {
-            return 2 * (li_ >> 3) * rowb + 2 * (8 * tile + (li_ & 7)) * PIXB + lh_ * (C::KPS / 2) * ES;
+            return 2 * (li_ >> 3) * lrow + 2 * (8 * tile + (li_ & 7)) * PIXB + lh_ * (C::KPS / 2) * ES;
         };
         auto epilogue = [&](const f32x16 &acc, int tile) {
             const int pw = 4 * tile + 2 * lh_;  // (8*tile + 4*lh) / 2
@@ -357,40 +413,44 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
                 max(max(y[1][2], y[2][2]), y[3][2]), max(max(y[1][3], y[2][3]), y[3][3]));
             put(row2, pw, y[3][0], y[3][1], y[3][2], y[3][3]);
         };
-
-        if (ntw == 0) {
-            duties();
-        } else {
-            // first tile: the chain carries the block's housekeeping
-            f32x16 acc;
+        // NT tiles one after the other, two accumulators taking turns: the chain of tile j carries
+        // the epilogue of tile j-1 in its instruction stream (and, at one kernel row, this wave's
+        // share of the housekeeping); only the last tile's epilogue has no matrix work beside it.
+        auto run_tiles = [&](auto nt_c) {
+            constexpr int NT = decltype(nt_c)::value;
+            f32x16 acc[2];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-            {
-                const int ab = abase_of(wm_);
+            for (int j = 0; j < NT; ++j) {
+                const int ab = abase_of(wm_ + 4 * j);
 #pragma unroll
                 for (int kh = 0; kh < kK; ++kh) {
-                    if (kh == 3) duties();
-                    mfma_row(acc, patch, ab + kh * rowb, kh);
+                    if (kh == 3) {
+                        if (j == 0) staged_patch();
+                        if (j == ship_tile) ship_mine();
+                    }
+                    if (kh == 1 && j > 0) epilogue(acc[(j - 1) & 1], wm_ + 4 * (j - 1));
+                    mfma_row(acc[j & 1], patch, ab + kh * lrow, kh);
                 }
+                if (j == 0) stamp(pj, 5);
             }
-            // tiles 1 ..: the chain of tile j carries the epilogue of tile j-1
-            for (int j = 1; j < ntw; ++j) {
-                const f32x16 prev = acc;
-                const int tile = wm_ + 4 * j;
-                const int ab = abase_of(tile);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-                mfma_row(acc, patch, ab, 0);
-                epilogue(prev, tile - 4);
-#pragma unroll
-                for (int kh = 1; kh < kK; ++kh) mfma_row(acc, patch, ab + kh * rowb, kh);
-            }
-            epilogue(acc, wm_ + 4 * (ntw - 1));
+            stamp(pj, 6);
+            epilogue(acc[(NT - 1) & 1], wm_ + 4 * (NT - 1));
+        };
+        switch (ntw) {
+            case 0: staged_patch(); ship_mine(); break;
+            case 1: run_tiles(std::integral_constant<int, 1>{}); break;
+            case 2: run_tiles(std::integral_constant<int, 2>{}); break;
+            case 3: run_tiles(std::integral_constant<int, 3>{}); break;
+            default: run_tiles(std::integral_constant<int, 4>{}); break;
         }
+        stamp(pj, 7);
+        if constexpr (!NCHW_IN) dma_landed();  // this wave's pieces of the next patch are in LDS
         __syncthreads();
+        stamp(pj, 8);
         patch_off = next_off;
     }
-    ship(pj1 - 1);  // the last item's pooled rows
+    // the last item's pooled rows
+    ship_row(2 * (pj1 - 1) + (wave >> 2));
 }
 
 // OIHW fp32 [64][3][7][7] -> the panel the kernel keeps in registers
@@ -486,6 +546,7 @@ static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, 
     p.PW = (int)PW;
     p.Cin = (int)Cin;
     p.pairs = (int)rn_ceil_div(PH, 2);
+    p.stamps = (unsigned long long *)ctx->debug_stamps;
     // A block walks seg_len items of one image; a segment that starts inside an image computes one
     // stem row more (the halo tile).  One block per CU (LDS): the launch takes ceil(blocks / CUs)
     // rounds of the longest block, so pick the segment length that minimises rounds x rows per block.
@@ -501,7 +562,16 @@ static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, 
         }
         p.segs = (int)rn_ceil_div((uint64_t)p.pairs, (uint64_t)p.seg_len);
     }
-    const size_t patch = 48 + (((size_t)kPatchRows * Wp * cs * es + 15) & ~(size_t)15);
+    p.lrow = (int)(Wp * cs * es);
+    p.ppr_mul = p.ppr_shr = 0;
+    if (dtype == RN_DTYPE_BF16 && !nchw) {
+        // pitch = 64 (mod 128); rows are whole 16-byte pieces (checked above)
+        p.lrow += (int)((64 + 128 - (p.lrow & 127)) & 127);
+        rn_fast_div((unsigned)(p.lrow / 16), &p.ppr_mul, &p.ppr_shr);
+    } else if (dtype == RN_DTYPE_BF16) {
+        p.lrow += (int)((64 + 128 - (p.lrow & 127)) & 127);  // the NCHW fetch writes pixel by pixel: any pitch
+    }
+    const size_t patch = 48 + (((size_t)kPatchRows * p.lrow + 15) & ~(size_t)15);
     RN_REQUIRE(ctx, patch <= 48 * 1024, "image too wide for the fused stem (patch)");
     const size_t lds_bytes = 2 * patch + (size_t)kRing * PW * kCout * sizeof(float);
     RN_REQUIRE(ctx, lds_bytes <= 160 * 1024, "image too wide for the fused stem (LDS)");
