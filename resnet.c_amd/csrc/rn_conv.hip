@@ -1275,6 +1275,12 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
                              ctx->layout == RN_LAYOUT_NHWC, 0, nullptr,
                              "rn_conv2d_forward(direct)");
     }
+    // 1x1 / stride 1 on NCHW tensors: NCHW is the MFMA's own layout with the operands swapped
+    // (rn_conv_nchw.hip) -- no transpose of the input, no packing of the weight, the same bits
+    if (ctx->layout == RN_LAYOUT_NCHW &&
+        rn_conv1x1_nchw_eligible(kernel_size, stride, padding, B, in_channels, out_channels, H, W) &&
+        (reinterpret_cast<uintptr_t>(weight) & 15) == 0 && h_out == (H - 1) / stride + 1 && w_out == (W - 1) / stride + 1)
+        return rn_conv1x1_nchw_launch(ctx, inp, out, weight, stride, B, in_channels, out_channels, H, W);
     // K-major panel of the OIHW weight: packed per call into scratch, or -- with the context's
     // weight cache on -- once per (weight buffer, shape) and kept until that buffer is freed or
     // written through the rn_* calls

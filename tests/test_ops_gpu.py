@@ -578,17 +578,31 @@ def test_one_thread_two_contexts_interleaved():
                                   (5, 64, 72, 7, 7, 1, 1, 0),        # 49 pixels per image: quads straddle images, unaligned planes
                                   (2, 128, 40, 9, 11, 3, 2, 1),      # K = 1152: chunked K sum, ragged channels
                                   (1, 3, 64, 32, 32, 7, 2, 3),       # small-Cin stem form
-                                  (40, 128, 64, 7, 7, 3, 1, 1)])     # chunked, more than one round of tiles: a tail that the NHWC route cuts
+                                  (40, 128, 64, 7, 7, 3, 1, 1),      # chunked, more than one round of tiles: a tail that the NHWC route cuts
+                                  # 1x1 / stride 1 with H*W % 4 == 0: the NCHW-native kernel (rn_conv_nchw.hip)
+                                  (3, 64, 256, 8, 8, 1, 1, 0),       # 128 x 128 tiles
+                                  (2, 256, 64, 14, 14, 1, 1, 0),     # 64 output channels: the 64 x 256 tile; tiles straddle images
+                                  (3, 1024, 200, 6, 6, 1, 1, 0),     # K = 1024: chunked sum; ragged channel tile
+                                  (5, 2048, 40, 2, 2, 1, 1, 0),      # chunked, 20 pixels in all, fewer channels than a tile
+                                  (7, 96, 136, 10, 10, 1, 1, 0),     # three K tiles, ragged everything
+                                  (2, 64, 64, 3, 3, 1, 1, 0),        # 9 pixels per image: one dword load per staged pixel
+                                  (3, 2048, 512, 7, 7, 1, 1, 0),     # 7x7 planes, chunked (layer4's conv1)
+                                  (2, 64, 128, 8, 8, 1, 2, 0),       # stride 2 (the projection shortcuts)
+                                  (3, 256, 72, 9, 7, 1, 2, 0),       # stride 2 on odd sizes
+                                  (2, 48, 64, 8, 8, 1, 1, 0)])       # Cin not a multiple of 32: the direct kernel, another order
 def test_nchw_route_writes_the_nhwc_routes_bits(case):
-    """rn_conv2d_forward on NCHW tensors transposes its input and lets the contraction's epilogue
-    write NCHW itself (GemmParams::out_nchw).  Same products and the same summation order as the
-    NHWC call -- also where the NHWC launch cuts its tail tiles into K chunks and a finishing
-    kernel adds them -- so the two layouts must agree bit for bit, and with the oracle."""
+    """rn_conv2d_forward on NCHW tensors: a 1x1 / padding-0 convolution runs on the NCHW-native
+    kernel (rn_conv_nchw.hip: weights = MFMA rows, pixels = columns, no transpose, no packing);
+    anything else transposes its input and lets the contraction's epilogue write NCHW itself
+    (GemmParams::out_nchw).  Same products and the same summation order as the NHWC call -- also
+    where the NHWC launch cuts its tail tiles into K chunks and a finishing kernel adds them -- so
+    the two layouts must agree bit for bit, and with the oracle."""
     B, Cin, Cout, H, W, k, s, p = case
     x, w = rnd((B, Cin, H, W), 300 + sum(case)), rnd((Cout, Cin, k, k), 301 + sum(case)) / np.sqrt(Cin * k * k)
     a = ops.conv2d(x, w, s, p, "nchw")
     if Cin >= 4:   # (an NHWC call with fewer than four channels takes the direct kernel: another order)
         assert np.array_equal(a, ops.conv2d(x, w, s, p, "nhwc"))
+    assert np.array_equal(a, ops.conv2d(x, w, s, p, "nchw"))
     if B * H * W <= 4000:
         want = O.conv2d(x, w, s, p)
         assert np.abs(a - want).max() <= 2e-6 * np.sqrt(Cin * k * k) * float(np.abs(want).max()) + 1e-6
