@@ -113,6 +113,11 @@ RN_API int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate);
  * summation order (and so the last bits) differs from the unsplit launch: 0 (default) keeps
  * results independent of the batch size.  Range 0..64. */
 RN_API int rn_ctx_set_split_k(rn_ctx *ctx, int max_splits);
+/* Fused stem + max-pool (rn_stem_pool_forward_dt): a block walks `items` consecutive items (four
+ * stem rows = two pooled rows each) of one image; 0 (default) = chosen per launch so that the
+ * blocks fill the device's CUs in the fewest rounds.  The bits do not depend on it: a block that
+ * starts inside an image computes the one stem row above its segment once more. */
+RN_API int rn_ctx_set_stem_items(rn_ctx *ctx, int items);
 /* Diagnostics: device buffer of 16 x uint64 per block that the contraction kernel fills with
  * wall-clock and shader-clock stamps of its phases (tools/conv_stamps.py); NULL (default) = off. */
 RN_API int rn_ctx_set_debug_stamps(rn_ctx *ctx, void *dev_buffer);

@@ -46,6 +46,7 @@ SIGNATURES = {
     "rn_conv_tile_candidates": (c_int, []),
     "rn_ctx_set_conv_tile": (c_int, [c_void_p, c_int]),
     "rn_ctx_set_split_k": (c_int, [c_void_p, c_int]),
+    "rn_ctx_set_stem_items": (c_int, [c_void_p, c_int]),
     "rn_ctx_set_debug_stamps": (c_int, [c_void_p, c_void_p]),
     "rn_ctx_stream": (c_void_p, [c_void_p]),
     "rn_ctx_device": (c_int, [c_void_p]),

@@ -241,6 +241,14 @@ int rn_ctx_set_split_k(rn_ctx *ctx, int max_splits)
     return RN_OK;
 }
 
+int rn_ctx_set_stem_items(rn_ctx *ctx, int items)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (items < 0) return rn_set_error(ctx, RN_ERR_INVALID, "stem items %d: 0 (chosen per launch) or a positive count", items);
+    ctx->stem_items = items;
+    return RN_OK;
+}
+
 // library-internal: everything queued on ctx's stream after this call waits for the event
 int rn_ctx_wait_event(rn_ctx *ctx, rn_event *ev)
 {

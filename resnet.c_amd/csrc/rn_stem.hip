@@ -560,6 +560,7 @@ static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, 
             const uint64_t cost = rounds * (4ull * (uint64_t)len + (segs > 1 ? 1 : 0) + 1);  // + start-up
             if (cost < best) best = cost, p.seg_len = len;
         }
+        if (ctx->stem_items > 0) p.seg_len = ctx->stem_items < p.pairs ? ctx->stem_items : p.pairs;  // rn_ctx_set_stem_items
         p.segs = (int)rn_ceil_div((uint64_t)p.pairs, (uint64_t)p.seg_len);
     }
     p.lrow = (int)(Wp * cs * es);

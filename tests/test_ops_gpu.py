@@ -653,14 +653,17 @@ def test_fp32_conv_chain_out_of_the_fused_pair_bit_for_bit(case):
     assert np.array_equal(got_t1, want_t1)
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 32, 32), (1, 3, 40, 48), (2, 2, 26, 16)])
+@pytest.mark.parametrize("shape", [(2, 3, 224, 224), (3, 3, 32, 32), (1, 3, 40, 48), (2, 2, 26, 16),
+                                   (1, 3, 256, 256),    # the widest image the launch takes (conv output width 128)
+                                   (300, 3, 64, 32)])   # more blocks than CUs; segments that start inside an image
 @pytest.mark.parametrize("bf16", [False, True])
 def test_fused_stem_and_maxpool_match_the_four_reference_ops(shape, bf16):
     """rn_stem_pool_forward_dt: conv 7x7/2 + batch-norm (folded) + ReLU + max-pool 3x3/2/1 as one
     launch (main.cu:179-192) against the oracle's four ops.  Odd row counts, the first pooled row
     (whose top window row does not exist), windows over the right and bottom edges, fewer than
-    three input channels; bf16: oracle on bf16-rounded operands, stem output rounded to bf16
-    before the pool as the unfused path does."""
+    three input channels, images cut into segments (a block then computes the stem row above its
+    segment once more), the pooled row that two consecutive items of a block share; bf16: oracle on
+    bf16-rounded operands, stem output rounded to bf16 before the pool as the unfused path does."""
     B, Cin, H, W = shape
     seed = 1200 + sum(shape)
     x, w = rnd(shape, seed), rnd((64, Cin, 7, 7), seed + 1) / np.sqrt(Cin * 49)
@@ -684,6 +687,35 @@ def test_fused_stem_and_maxpool_match_the_four_reference_ops(shape, bf16):
     if not bf16 and Cin == 3:
         conv = ops.conv2d_nhwc_fused(x, w, 2, 3, sc, sh, None, True)
         assert np.abs(got - ops.maxpool2d(conv, 3, 2, 1, "nhwc")).max() <= tol
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_fused_stem_segments_change_blocks_not_results(bf16):
+    """A block of the fused stem walks a segment of an image and carries the pooled row two
+    consecutive items share in LDS; a segment that starts inside an image recomputes the stem row
+    above it.  Whatever the segment length (rn_ctx_set_stem_items), the bits are the same -- odd
+    row counts and the last, partial item included."""
+    from resnet_c_amd import _lib as L
+    ctx, lib = R.get_ctx(), L.lib()
+    for shape in ((2, 3, 224, 224), (3, 3, 90, 48), (1, 2, 58, 64)):
+        x, w = rnd(shape, 77 + shape[2]), rnd((64, shape[1], 7, 7), 78) / np.sqrt(shape[1] * 49)
+        sc, sh = np.linspace(0.5, 1.5, 64, dtype=np.float32), np.linspace(-0.3, 0.3, 64, dtype=np.float32)
+        if bf16:
+            x, w = ops.bf16_round(x), ops.bf16_round(w)
+        try:
+            outs = []
+            for items in (1, 2, 3, 5, 100, 0):
+                L.check(lib.rn_ctx_set_stem_items(ctx.handle, items), "items", ctx.handle)
+                outs.append(ops.stem_pool(x, w, sc, sh, True, bf16=bf16))
+                outs.append(ops.stem_pool(x, w, sc, sh, True, bf16=bf16, from_nchw=True))
+        finally:
+            lib.rn_ctx_set_stem_items(ctx.handle, 0)
+        for o in outs[1:]:
+            assert np.array_equal(o, outs[0])
+        y = O.relu_(O.conv2d(x, w, 2, 3) * sc[None, :, None, None] + sh[None, :, None, None])
+        want = O.maxpool2d(ops.bf16_round(y) if bf16 else y, 3, 2, 1)
+        assert np.abs(outs[0] - want).max() <= (2 ** -7 if bf16 else 3e-5) * float(np.abs(want).max()) + 1e-6
+    assert lib.rn_ctx_set_stem_items(ctx.handle, -1) == L.RN_ERR_INVALID
 
 
 def test_fused_stem_refuses_what_it_cannot_do():

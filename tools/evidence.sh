@@ -4,8 +4,7 @@
 #   tools/evidence.sh [bench|trace|pmc|all]
 what=${1:-all}
 o=gpurun_out/ev
-rm -rf $o
-mkdir -p $o
+mkdir -p $o   # (one phase per gpurun call fits the call's time limit; the phases do not share files)
 export TMPDIR=/tmp
 if [ $what = bench ] || [ $what = all ]; then
   python bench.py > $o/bench_f32.json 2> $o/bench_f32.err
@@ -17,6 +16,9 @@ if [ $what = bench ] || [ $what = all ]; then
   python tools/layer_report.py --tune > $o/layers_f32.txt 2>&1
   python tools/layer_report.py --tune --dtype bf16 > $o/layers_bf16.txt 2>&1
   python tools/veneer_rate.py --batch 256 --steps 3 > $o/dropin_route_rates.txt 2>&1
+  python tools/stem_bench.py > $o/stem_pool_alone.txt 2>&1
+  python tools/stem_stamps.py --dtype bf16 > $o/stem_pool_stamps_bf16.txt 2>&1
+  python tools/stem_stamps.py --dtype f32 > $o/stem_pool_stamps_f32.txt 2>&1
 fi
 if [ $what = trace ] || [ $what = all ]; then
   for dt in f32 bf16; do
