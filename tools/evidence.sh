@@ -16,6 +16,7 @@ if [ $what = bench ] || [ $what = all ]; then
   python tools/layer_report.py --tune > $o/layers_f32.txt 2>&1
   python tools/layer_report.py --tune --dtype bf16 > $o/layers_bf16.txt 2>&1
   python tools/veneer_rate.py --batch 256 --steps 3 > $o/dropin_route_rates.txt 2>&1
+  python tools/shard_rate.py > $o/shard_upload_rates.txt 2>&1
   python tools/stem_bench.py > $o/stem_pool_alone.txt 2>&1
   python tools/stem_stamps.py --dtype bf16 > $o/stem_pool_stamps_bf16.txt 2>&1
   python tools/stem_stamps.py --dtype f32 > $o/stem_pool_stamps_f32.txt 2>&1
