@@ -115,6 +115,11 @@ void rn_conv_wide_launch(rn_ctx *ctx, rn_gemm::GemmParams &p, int which, bool du
 bool rn_conv_strip_eligible(const rn_gemm::GemmParams &p);
 void rn_conv_strip_launch(rn_ctx *ctx, const rn_gemm::GemmParams &p);
 
+// fp32 3x3 / stride 1 / 64 -> 64 channels with the weights in registers and the input in a rolling LDS
+// ring (rn_conv_strip32.hip): the fp32 model's stage-1 conv2; same bits as the tile kernels.
+bool rn_conv_strip32_eligible(const rn_gemm::GemmParams &p);
+void rn_conv_strip32_launch(rn_ctx *ctx, const rn_gemm::GemmParams &p);
+
 // fp32 1x1 / padding 0 convolution on NCHW tensors with the OIHW weight as it is (rn_conv_nchw.hip):
 // the literal drop-in route's rn_conv2d_forward without the input transpose.  Same bits as the
 // NHWC contraction.
