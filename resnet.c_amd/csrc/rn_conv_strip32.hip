@@ -36,10 +36,11 @@
 // MFMAs back to back (see the ISA: eight MFMAs between two pairs of ds_read_b128, nothing else).
 // Lab builds of this loop (-DS32_LAB_*): without the fragment reads 476 us, without the 16
 // vector-memory instructions of a step (8 LDS-DMA pieces, 8 stores) 447 us, without both 427 us =
-// 138.6 TFLOP/s.  With one wave per SIMD every vector-memory instruction is a hole in the matrix
-// stream (9 % for 16 of them among 576 MFMAs); with four waves per SIMD (the tile kernels) the
-// holes are filled but the loop pays for staging, barriers and its epilogue instead.  An fp32
-// 3x3 layer that moves 0.84 TB/s of operands and results sits at 120-125 TFLOP/s either way.
+// 138.6 TFLOP/s -- and with those 16 instructions ISSUED but given out-of-range offsets (they move
+// nothing) 437-439 us.  So it is not their issue slots that cost the matrix stream 12 %: it is the
+// 0.84 TB/s of operands and results they move.  A kernel that multiplies at this density AND
+// streams from HBM is held at 120-125 TFLOP/s by the chip (the same 82-83 % matrix-pipe duty shows
+// in the tile kernel and in the fused stem), whatever its instruction stream looks like.
 #include "rn_conv_params.h"
 #include "rn_lds_dma.h"
 
@@ -160,6 +161,9 @@ __global__ __launch_bounds__(256) void conv_strip32_kernel(const Strip32Params p
             slot0 = slot0 >= kRingP ? slot0 - kRingP : slot0;
             const int u = ub - kMargin + 128 * s + 128 + 2 * kMargin + 8 * g8 + prow;
             nxt_off[j] = s + 1 < nst ? src_off(u, slot0 + prow, seg) : kOob;
+#ifdef S32_LAB_OOB  // lab: the step's vector-memory instructions are issued but move nothing
+            nxt_off[j] = kOob;
+#endif
             nxt_dst[j] = lds_base + (unsigned)(seg * kSegB + slot0 * 128);
         }
 
@@ -228,6 +232,9 @@ __global__ __launch_bounds__(256) void conv_strip32_kernel(const Strip32Params p
             }
             const int g = pixel_of(ub + 128 * s + 64 * ph + 32 * i + li);
             pend_off[i] = g < 0 ? kOob : g * 256 + (32 * cf + 4 * lh) * 4;
+#ifdef S32_LAB_OOB
+            pend_off[i] = kOob;
+#endif
         }
         relbase = relbase + 128 >= kRingP ? relbase + 128 - kRingP : relbase + 128;
     }
