@@ -174,6 +174,40 @@ __global__ __launch_bounds__(kBlock) void pool_nhwc_bf16_kernel(
     }
 }
 
+// Global k x k average (avgPool2dKernel ops.cu:80-108 as the network uses it, main.cu:120,213: 7x7 over
+// a 7x7 image): one output pixel per image, every tap inside.  A lane owns V = 16 bytes of channels;
+// all TAPS loads are issued before the first add -- 49 independent 16-byte loads in flight per lane
+// instead of a row of seven at a time (the launch is 27 us for 103 MB: memory parallelism is all it
+// has) -- then the taps are added one by one in the reference's kh-major order and divided by k twice.
+template <typename E, int N, int TAPS>
+__global__ __launch_bounds__(kBlock) void avgpool_global_kernel(const void *__restrict__ inp, void *__restrict__ outp,
+                                                                int CV, float kf, uint64_t total)
+{
+    typedef E V __attribute__((ext_vector_type(N)));
+    const V *in = static_cast<const V *>(inp);
+    V *out = static_cast<V *>(outp);
+    const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += gstride) {
+        const uint64_t b = i / (uint64_t)CV, c = i - b * (uint64_t)CV;
+        const V *src = in + b * (uint64_t)TAPS * (uint64_t)CV + c;
+        V v[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) v[t] = __builtin_nontemporal_load(src + (size_t)t * CV);
+        __builtin_amdgcn_sched_barrier(0);  // every load issued before the first add (else hipcc folds them into the chain)
+        float acc[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[j] += (float)v[t][j];
+        V o;
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] = (E)(acc[j] / kf / kf);
+        out[i] = o;
+    }
+}
+
 // 3x3 max-pool whose every window holds at least one real pixel (the network's pool after the
 // stem, ops.cu:50-78 with k 3, stride 2, padding 1).  A padded tap is replaced by the nearest
 // pixel inside the image, which is a tap of the same window already, so the maximum -- NaN
@@ -251,6 +285,11 @@ int pool_bf16_dispatch(rn_ctx *ctx, const void *inp, void *out, uint64_t k, uint
             inp, out, (int)stride, (int)pad, (int)h_out, (int)w_out, (int)(C / 8), (int)H, (int)W, total8);
         return rn_after_launch(ctx, what);
     }
+    if (!kMax && k == 7 && H == 7 && W == 7 && pad == 0 && h_out == 1 && w_out == 1) {
+        avgpool_global_kernel<bf16_t, 8, 49><<<rn_stream_grid(total8, kBlock), kBlock, 0, ctx->stream>>>(
+            inp, out, (int)(C / 8), 7.f, total8);
+        return rn_after_launch(ctx, what);
+    }
     pool_nhwc_bf16_kernel<kMax><<<rn_stream_grid(total8, kBlock), kBlock, 0, ctx->stream>>>(
         (const bf16_t *)inp, (bf16_t *)out, (int)k, (int)stride, (int)pad, (int)h_out, (int)w_out,
         (int)(C / 8), (int)H, (int)W, total8);
@@ -279,6 +318,11 @@ int pool_dispatch(rn_ctx *ctx, const float *inp, float *out, uint64_t k, uint64_
         if (kMax && k == 3 && windows_never_empty(k, stride, pad, h_out, w_out, H, W)) {
             maxpool3_nhwc_kernel<float, 4><<<rn_stream_grid(total4, kBlock), kBlock, 0, ctx->stream>>>(
                 inp, out, (int)stride, (int)pad, (int)h_out, (int)w_out, (int)(C / 4), (int)H, (int)W, total4);
+            return rn_after_launch(ctx, what);
+        }
+        if (!kMax && k == 7 && H == 7 && W == 7 && pad == 0 && h_out == 1 && w_out == 1) {
+            avgpool_global_kernel<float, 4, 49><<<rn_stream_grid(total4, kBlock), kBlock, 0, ctx->stream>>>(
+                inp, out, (int)(C / 4), 7.f, total4);
             return rn_after_launch(ctx, what);
         }
         pool_nhwc_vec_kernel<kMax><<<rn_stream_grid(total4, kBlock), kBlock, 0, ctx->stream>>>(
