@@ -134,17 +134,18 @@ __device__ __forceinline__ float bn_apply_reg(float x, const BnParams &p)
 }
 
 // NCHW, N % 4 == 0: one wave walks one (b, c) plane at a time, so the channel's five
-// doubles are wave-uniform (scalar registers) and the lanes stream the plane as float4.
-__global__ __launch_bounds__(kBlock) void bn_nchw_vec_kernel(const float *inp, float *out,
-                                                             const double *__restrict__ params,
-                                                             uint32_t planes, uint32_t n4,
-                                                             uint32_t C)
+// doubles are wave-uniform and the lanes stream the plane as float4.  The constants are derived
+// from the layer's tensors at the top of each plane (one square root and one division per plane
+// of hundreds of pixels) instead of by a separate launch per call.
+__global__ __launch_bounds__(kBlock) void bn_nchw_vec_kernel(const float *inp, float *out, uint32_t planes,
+                                                             uint32_t n4, uint32_t C, const float *weight,
+                                                             const float *bias, const float *mean, const float *var)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
     const uint32_t nwaves = gridDim.x * (kBlock / 64);
     for (uint32_t plane = wave; plane < planes; plane += nwaves) {
-        const BnParams p = bn_load(params + kBnStride * (uint64_t)(plane % C));
+        const BnParams p = bn_derive(weight, bias, mean, var, plane % C);
         const f32x4 *in4 = reinterpret_cast<const f32x4 *>(inp) + (uint64_t)plane * n4;
         f32x4 *out4 = reinterpret_cast<f32x4 *>(out) + (uint64_t)plane * n4;
         for (uint32_t i = lane; i < n4; i += 64) {
@@ -155,6 +156,24 @@ __global__ __launch_bounds__(kBlock) void bn_nchw_vec_kernel(const float *inp, f
             v.w = bn_apply_reg(v.w, p);
             __builtin_nontemporal_store(v, &out4[i]);
         }
+    }
+}
+
+// NCHW, any plane size (7x7 = 49 pixels is not a multiple of 4, and such planes are not 16-byte
+// aligned): the same walk with one float per lane.  A plane is one contiguous run, so a wave's
+// loads are whole cache lines; no per-element division to find the channel.
+__global__ __launch_bounds__(kBlock) void bn_nchw_plane_kernel(const float *inp, float *out, uint32_t planes,
+                                                               uint32_t N, uint32_t C, const float *weight,
+                                                               const float *bias, const float *mean, const float *var)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBlock + threadIdx.x) >> 6);
+    const uint32_t nwaves = gridDim.x * (kBlock / 64);
+    for (uint32_t plane = wave; plane < planes; plane += nwaves) {
+        const BnParams p = bn_derive(weight, bias, mean, var, plane % C);
+        const float *in = inp + (uint64_t)plane * N;
+        float *o = out + (uint64_t)plane * N;
+        for (uint32_t i = lane; i < N; i += 64) o[i] = bn_apply_reg(in[i], p);
     }
 }
 
@@ -326,9 +345,12 @@ int rn_batchnorm2d_forward(rn_ctx *ctx, const float *inp, float *out, const floa
     } else if (ctx->layout == RN_LAYOUT_NCHW && al && N % 4 == 0 && B * C < (1ull << 32)) {
         const uint64_t planes = B * C;
         const unsigned grid = rn_stream_grid(planes * 64, kBlock);
-        prep();
-        bn_nchw_vec_kernel<<<grid, kBlock, 0, ctx->stream>>>(inp, out, params, (uint32_t)planes,
-                                                             (uint32_t)(N / 4), (uint32_t)C);
+        bn_nchw_vec_kernel<<<grid, kBlock, 0, ctx->stream>>>(inp, out, (uint32_t)planes, (uint32_t)(N / 4),
+                                                             (uint32_t)C, weight, bias, mean, var);
+    } else if (ctx->layout == RN_LAYOUT_NCHW && B * C < (1ull << 32)) {
+        const uint64_t planes = B * C;
+        bn_nchw_plane_kernel<<<rn_stream_grid(planes * 64, kBlock), kBlock, 0, ctx->stream>>>(
+            inp, out, (uint32_t)planes, (uint32_t)N, (uint32_t)C, weight, bias, mean, var);
     } else {
         prep();
         bn_scalar_kernel<<<rn_stream_grid(total, kBlock), kBlock, 0, ctx->stream>>>(

@@ -257,6 +257,64 @@ __global__ __launch_bounds__(kBlock) void maxpool3_nhwc_kernel(const void *__res
     }
 }
 
+// ---- NCHW forms of the network's two pools (the literal drop-in route; cuda/nn.cu:31-53 on NCHW) ----
+//
+// Global 7x7 average over NCHW planes of 49 contiguous floats: a block loads 256 planes as one
+// contiguous run (coalesced dwords) into LDS, then lane l adds plane l's 49 taps in memory order =
+// the reference's kh-major order (49 l + t: odd pitch, conflict-free).  pool_scalar_kernel put its
+// lanes along a 1-pixel-wide output row: 0.37 ms for 103 MB.
+template <int TAPS>
+__global__ __launch_bounds__(kBlock) void avgpool_global_nchw_kernel(const float *__restrict__ inp,
+                                                                     float *__restrict__ out, uint64_t planes, float kf)
+{
+    __shared__ float tile[kBlock * TAPS];
+    const uint64_t p0 = (uint64_t)blockIdx.x * kBlock;
+    const uint64_t n = min((uint64_t)kBlock, planes - p0) * TAPS;
+    const float *src = inp + p0 * TAPS;
+    for (uint64_t i = threadIdx.x; i < n; i += kBlock) tile[i] = src[i];
+    __syncthreads();
+    if (p0 + threadIdx.x < planes) {
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc += tile[threadIdx.x * TAPS + t];
+        out[p0 + threadIdx.x] = acc / kf / kf;
+    }
+}
+
+// 3x3 / stride 2 / padding 1 max-pool on NCHW planes whose width is a multiple of 8: a lane owns four
+// adjacent outputs of one row and reads, per input row, two aligned float4 and the one column to
+// their left -- 9 loads for 4 outputs where the scalar kernel issues 36 stride-2 dword loads.
+// -inf start and fmaxf: a padded tap (skipped here, skipped by the reference: ops.cu:65-67) never wins.
+__global__ __launch_bounds__(kBlock) void maxpool3s2_nchw_kernel(const float *__restrict__ inp, float *__restrict__ out,
+                                                                 int H, int W, int Ho, int Q, uint64_t total)
+{
+    const uint64_t gstride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i64 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i64 < total; i64 += gstride) {
+        const uint32_t i = (uint32_t)i64;
+        const int j = (int)(i % (uint32_t)Q);
+        const uint32_t r = i / (uint32_t)Q;
+        const int oh = (int)(r % (uint32_t)Ho);
+        const uint64_t plane = r / (uint32_t)Ho;
+        const float *base = inp + plane * (uint64_t)H * W + 8 * j;
+        float o0 = -INFINITY, o1 = -INFINITY, o2 = -INFINITY, o3 = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = 2 * oh - 1 + kh;
+            if (ih < 0 || ih >= H) continue;
+            const float *row = base + (size_t)ih * W;
+            const float4 a = *reinterpret_cast<const float4 *>(row), b = *reinterpret_cast<const float4 *>(row + 4);
+            const float e = j > 0 ? row[-1] : -INFINITY;
+            // tap order kw = 0, 1, 2 within the window, rows outermost: the reference's
+            o0 = fmaxf(fmaxf(fmaxf(o0, e), a.x), a.y);
+            o1 = fmaxf(fmaxf(fmaxf(o1, a.y), a.z), a.w);
+            o2 = fmaxf(fmaxf(fmaxf(o2, a.w), b.x), b.y);
+            o3 = fmaxf(fmaxf(fmaxf(o3, b.y), b.z), b.w);
+        }
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f32x4{o0, o1, o2, o3}, reinterpret_cast<f32x4 *>(out + (plane * Ho + oh) * (uint64_t)(4 * Q) + 4 * j));
+    }
+}
+
 // every window of the pooling geometry holds a real pixel, in both dimensions
 static bool windows_never_empty(uint64_t k, uint64_t stride, uint64_t pad, uint64_t h_out, uint64_t w_out,
                                 uint64_t H, uint64_t W)
@@ -328,6 +386,16 @@ int pool_dispatch(rn_ctx *ctx, const float *inp, float *out, uint64_t k, uint64_
         pool_nhwc_vec_kernel<kMax><<<rn_stream_grid(total4, kBlock), kBlock, 0, ctx->stream>>>(
             inp, out, (int)k, (int)stride, (int)pad, (int)h_out, (int)w_out, (int)(C / 4), (int)H,
             (int)W, total4);
+    } else if (ctx->layout == RN_LAYOUT_NCHW && !kMax && k == 7 && H == 7 && W == 7 && pad == 0 && h_out == 1 &&
+               w_out == 1) {
+        const uint64_t planes = B * C;
+        avgpool_global_nchw_kernel<49><<<(unsigned)rn_ceil_div(planes, kBlock), kBlock, 0, ctx->stream>>>(inp, out, planes,
+                                                                                                          7.f);
+    } else if (ctx->layout == RN_LAYOUT_NCHW && kMax && k == 3 && stride == 2 && pad == 1 && W % 8 == 0 && al &&
+               w_out == W / 2 && h_out == (H - 1) / 2 + 1 && total / 4 < (1ull << 32)) {
+        const uint64_t total4 = total / 4;  // one lane per four adjacent outputs
+        maxpool3s2_nchw_kernel<<<rn_stream_grid(total4, kBlock), kBlock, 0, ctx->stream>>>(
+            inp, out, (int)H, (int)W, (int)h_out, (int)(w_out / 4), total4);
     } else {
         pool_scalar_kernel<kMax><<<rn_stream_grid(total, kBlock), kBlock, 0, ctx->stream>>>(
             inp, out, (int)k, (int)stride, (int)pad, (int)h_out, (int)w_out, (int)C, (int)H,

@@ -193,7 +193,8 @@ def test_batchnorm_fold_entry_point():
 
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
 @pytest.mark.parametrize("case", [(2, 64, 112, 112, 3, 2, 1), (2, 6, 9, 9, 3, 2, 1), (1, 8, 7, 7, 2, 2, 0),
-                                  (3, 5, 8, 6, 3, 1, 1), (2, 2048, 7, 7, 7, 1, 0), (1, 12, 7, 7, 7, 1, 0)])
+                                  (3, 5, 8, 6, 3, 1, 1), (2, 2048, 7, 7, 7, 1, 0), (1, 12, 7, 7, 7, 1, 0),
+                                  (3, 5, 13, 24, 3, 2, 1), (1, 300, 7, 7, 7, 1, 0), (2, 3, 6, 8, 3, 2, 1)])
 def test_pools_bit_exact(case, layout):
     B, C, H, W, k, s, p = case
     x = rnd((B, C, H, W), 7 + sum(case))
@@ -208,10 +209,19 @@ def test_maxpool_all_padding_window_and_nan():
     for layout in ("nchw", "nhwc"):
         got = ops.maxpool2d(x, 3, 2, 1, layout)
         assert np.array_equal(got, O.maxpool2d(x, 3, 2, 1)) and not np.isnan(got).any()
+    # the vectorised NCHW form (width a multiple of 8): NaNs and -inf in every tap position of a lane's quad
+    y = rnd((2, 3, 10, 16), 99)
+    y[0, 0, 3, :] = np.nan
+    y[1, 2, :, 7] = np.nan
+    y[0, 1, 0:3, 0:3] = -np.inf
+    for layout in ("nchw", "nhwc"):
+        got = ops.maxpool2d(y, 3, 2, 1, layout)
+        assert np.array_equal(got, O.maxpool2d(y, 3, 2, 1)) and not np.isnan(got).any()
 
 
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
-@pytest.mark.parametrize("shape", [(2, 64, 56, 56), (3, 7, 5, 5), (1, 256, 14, 14), (2, 5, 4, 6), (4, 8, 1, 1)])
+@pytest.mark.parametrize("shape", [(2, 64, 56, 56), (3, 7, 5, 5), (1, 256, 14, 14), (2, 5, 4, 6), (4, 8, 1, 1),
+                                   (3, 2048, 7, 7), (70, 5, 9, 9)])
 def test_batchnorm_matches_double_expression(shape, layout):
     g = np.random.default_rng(sum(shape))
     x = g.standard_normal(shape, dtype=np.float32) * 3
