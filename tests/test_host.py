@@ -155,3 +155,44 @@ def test_shard_bounds_of_the_c_driver_match_bench():
                 assert lo.value == prev and hi.value - lo.value in (B // world, B // world + 1)
                 prev = hi.value
             assert prev == B
+
+
+def test_bench_quotes_pmc_traffic_only_for_the_build_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from committed rocprofv3 --pmc passes; the file carries the digest of the
+    kernel sources and its launch count, and bench.py must say null + stale for any other build."""
+    import argparse
+    import json
+
+    import bench
+
+    d = tmp_path / "profiles" / "round9"
+    d.mkdir(parents=True)
+    digest = L.source_digest()
+    assert re.fullmatch(r"[0-9a-f]{16}", digest) and digest == L.source_digest()
+    rec = {"traffic_bytes_per_launch": 123456789.4, "launches": 69, "source_digest": digest}
+    (d / "final_hbm_traffic_pmc.json").write_text(json.dumps(rec))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    args = argparse.Namespace(arch="resnet50", batch=256, mode="fused", dtype="f32")
+    assert bench.pmc_traffic(args, 69) == (123456789, os.path.join("profiles", "round9", "final_hbm_traffic_pmc.json"), False)
+    assert bench.pmc_traffic(args, 71)[0] == 123456789          # the tuner's tile picks move the count by a few
+    assert bench.pmc_traffic(args, 90)[0] is None and bench.pmc_traffic(args, 90)[2] is True
+    rec["source_digest"] = "0" * 16                              # measured on other kernel sources
+    (d / "final_hbm_traffic_pmc.json").write_text(json.dumps(rec))
+    value, src, stale = bench.pmc_traffic(args, 69)
+    assert value is None and stale is True and src.endswith("final_hbm_traffic_pmc.json")
+    args.dtype = "bf16"                                          # no file for this configuration
+    assert bench.pmc_traffic(args, 45) == (None, None, False)
+    args = argparse.Namespace(arch="resnet101", batch=64, mode="fused", dtype="f32")
+    assert bench.pmc_traffic(args, 10) == (None, None, False)
+
+
+def test_committed_pmc_traffic_is_that_of_the_committed_kernel_sources():
+    """The traffic files under the newest profiles/roundN must describe HEAD's kernels: a kernel change
+    without a fresh PMC pass would make the driver-run bench line say traffic_stale."""
+    import glob
+    import json
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "final_hbm_traffic_pmc.json")))
+    assert files
+    rec = json.load(open(files[-1]))
+    assert rec["source_digest"] == L.source_digest(), "re-run tools/evidence.sh pmc and commit profiles/"
