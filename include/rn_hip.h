@@ -31,10 +31,13 @@
  *
  * Layout.  The reference is NCHW everywhere.  With the context in
  * RN_LAYOUT_NCHW (default) every op reads and writes exactly what the
- * reference kernel does.  The engine itself runs NHWC: in RN_LAYOUT_NHWC the
- * same entry points take [B,H,W,C] activations (shape arguments unchanged),
- * and rn_conv2d_nhwc_forward takes weights pre-packed by
- * rn_conv2d_pack_weight plus an optional fused epilogue.
+ * reference kernel does: 1x1 / padding-0 convolutions on an NCHW-native
+ * contraction that takes the OIHW weight as it is, other convolutions through
+ * a transpose of their input into context scratch, batch-norm and the
+ * network's two pools on NCHW forms of their own.  The engine itself runs
+ * NHWC: in RN_LAYOUT_NHWC the same entry points take [B,H,W,C] activations
+ * (shape arguments unchanged), and rn_conv2d_nhwc_forward takes weights
+ * pre-packed by rn_conv2d_pack_weight plus an optional fused epilogue.
  *
  * Aliasing: out == inp is allowed for relu, batchnorm2d and add (out may alias
  * inp1), as the reference driver uses them (main.cu:138,145-146,162-163).
@@ -95,7 +98,8 @@ RN_API int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on);
 /* Tile shape of the contraction kernel: 0 = chosen per launch (default), 1..N = force
  * candidate i (all candidates give bit-identical results; used by rn_model_tune). */
 /* rn_conv2d_forward (the reference's OIHW / NCHW signature) re-packs the weight into the
- * engine's K-major panel on every call.  With the cache on, the panel is packed once per
+ * engine's K-major panel on every call (not for 1x1 convolutions on NCHW tensors: their kernel
+ * reads the OIHW buffer itself).  With the cache on, the panel is packed once per
  * (weight buffer, shape) and reused; entries die when the buffer is rn_free'd or written by
  * rn_memcpy_h2d / rn_memcpy_d2d / rn_memset.  A caller that turns it on promises not to change
  * a weight buffer by any other means (the reference's layers own their weights and never
@@ -334,8 +338,9 @@ RN_API int rn_conv2d_nhwc_exact_forward(rn_ctx *ctx, const float *inp_padded, fl
  * LDS integer maxima of the non-negative ReLU outputs.  inp_padded: NHWC image that carries its
  * own 3-pixel zero border (rn_nchw_to_nhwc_pad_dt with border 3; Cpad = 3 for fp32, 4 for
  * bf16), [B,Hp,Wp,Cpad]; out: [B,PH,PW,64] of `dtype`.  Needs 64 output channels, a conv
- * output width that is a multiple of 8 and at most 128 (ResNet: 112).  scale/shift: per
- * channel, nullable.  Same products as conv + bn + relu + maxpool, summed in another order.
+ * output width that is a multiple of 8 and at most 128 (ResNet: 112), any height; bf16: an even
+ * Wp.  A block walks down an image (or a segment of it, rn_ctx_set_stem_items) and carries the
+ * pooled row two consecutive row groups share in LDS.  scale/shift: per channel, nullable.  Same products as conv + bn + relu + maxpool, summed in another order.
  * relu must be non-zero (RN_ERR_INVALID otherwise): the pool is taken as an integer maximum of
  * the non-negative ReLU outputs' bit patterns. */
 RN_API uint64_t rn_stem_pool_packed_weight_numel(int dtype);
@@ -481,7 +486,9 @@ RN_API int rn_shard_tune(rn_shard *g, const float *host_input_nchw, uint64_t B, 
  * by the device's own host thread, all devices in parallel); collect returns the oldest batch,
  * rows in image order.  rn_shard_stream_buffer gives shard `rank`'s pinned staging buffer of the
  * NEXT submit and the image range [lo, hi) it holds: a decoder that writes there and submits
- * NULL saves the host-side copy.  At most two batches in flight (RN_ERR_INVALID otherwise). */
+ * NULL saves the host-side copy.  At most two batches in flight (RN_ERR_INVALID otherwise).
+ * rn_shard_forward re-sizes the per-device pipelines for its own chunks: it is refused while
+ * submitted batches are in flight, and a stream must be opened again after it. */
 RN_API int rn_shard_stream_open(rn_shard *g, uint64_t B, int mode);
 RN_API int rn_shard_stream_buffer(rn_shard *g, int rank, float **host_staging, uint64_t *lo,
                                   uint64_t *hi);

@@ -526,9 +526,10 @@ static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, 
         RN_REQUIRE(ctx, (Wp - 6) % 4 == 0, "NCHW input: the image width must be a multiple of 4");
         RN_REQUIRE(ctx, (Wp - 6) / 4 <= 64, "image too wide for the fused stem (NCHW fetch: W <= 256)");
     } else {
-        // the patch copy moves 16-byte pieces from the 16-byte boundary below a row start
-        RN_REQUIRE(ctx, (Wp * cs * es) % (dtype == RN_DTYPE_BF16 ? 16 : 8) == 0,
-                   "padded image width must make rows a multiple of 16 bytes (bf16) / 8 bytes (fp32)");
+        // bf16 rows land in LDS piece by piece at a pitch of their own: whole 16-byte pieces per row.
+        // (fp32 rows are copied as one flat block from the 16-byte boundary below it: any width.)
+        RN_REQUIRE(ctx, dtype != RN_DTYPE_BF16 || (Wp * cs * es) % 16 == 0,
+                   "bf16: the padded image width must be even (rows of whole 16-byte pieces)");
     }
     RN_REQUIRE(ctx, B * Hp * Wp * cs < (1ull << 40) && B * PH * PW < (1ull << 31), "tensor too large");
     StemParams p;

@@ -728,6 +728,37 @@ def test_fused_stem_segments_change_blocks_not_results(bf16):
     assert lib.rn_ctx_set_stem_items(ctx.handle, -1) == L.RN_ERR_INVALID
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_fused_stem_random_geometries(seed):
+    """Random image sizes (odd and even heights; both widths behind a conv output width of 8 .. 64 in
+    fp32 -- bf16 rows must be whole 16-byte pieces: even widths), channel counts, batch sizes and segment
+    lengths, both input forms, against the oracle's four ops."""
+    from resnet_c_amd import _lib as L
+    g = np.random.default_rng(4242 + seed)
+    bf16 = bool(seed & 1)
+    wo = 8 * int(g.integers(1, 9))
+    W = 2 * wo - (0 if bf16 else int(g.integers(0, 2)))
+    H = int(g.integers(7, 100))
+    B, Cin = int(g.integers(1, 5)), int(g.integers(1, 4))
+    x, w = rnd((B, Cin, H, W), 5000 + seed), rnd((64, Cin, 7, 7), 5100 + seed) / np.sqrt(Cin * 49)
+    sc, sh = g.random(64, dtype=np.float32) + 0.5, g.standard_normal(64, dtype=np.float32) * 0.3
+    if bf16:
+        x, w = ops.bf16_round(x), ops.bf16_round(w)
+    y = O.relu_(O.conv2d(x, w, 2, 3) * sc[None, :, None, None] + sh[None, :, None, None])
+    want = O.maxpool2d(ops.bf16_round(y) if bf16 else y, 3, 2, 1)
+    ctx, lib = R.get_ctx(), L.lib()
+    try:
+        for items in (0, int(g.integers(1, 9))):
+            L.check(lib.rn_ctx_set_stem_items(ctx.handle, items), "items", ctx.handle)
+            for nchw in ((False, True) if W % 4 == 0 else (False,)):
+                got = ops.stem_pool(x, w, sc, sh, True, bf16=bf16, from_nchw=nchw)
+                assert got.shape == want.shape, (B, Cin, H, W)
+                tol = (2 ** -7 if bf16 else 2e-6 * np.sqrt(Cin * 49)) * float(np.abs(want).max()) + 1e-6
+                assert np.abs(got - want).max() <= tol, (B, Cin, H, W, items, nchw)
+    finally:
+        lib.rn_ctx_set_stem_items(ctx.handle, 0)
+
+
 def test_fused_stem_refuses_what_it_cannot_do():
     from resnet_c_amd import _lib as L
     x, w = rnd((1, 3, 30, 30), 5), rnd((64, 3, 7, 7), 6)
@@ -829,3 +860,21 @@ def test_fp32_strip_kernel_full_size_under_load():
         assert np.array_equal(fetch(), want)
     finally:
         lib.rn_ctx_set_conv_tile(ctx.handle, 0)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_nchw_native_1x1_random_shapes(seed):
+    """rn_conv_nchw.hip on random shapes: any batch, plane size (quads that straddle images, planes
+    that are not 16-byte multiples), channel counts around the tile edges, strides 1-3, K below and
+    above the chunked-sum threshold -- bit for bit the NHWC contraction, and within tolerance of the
+    oracle."""
+    g = np.random.default_rng(777 + seed)
+    B, H, W = int(g.integers(1, 6)), int(g.integers(1, 20)), int(g.integers(1, 20))
+    Cin = 32 * int(g.choice([1, 2, 3, 8, 16, 32, 40]))
+    Cout = int(g.choice([1, 7, 63, 64, 65, 127, 128, 129, 200, 300]))
+    stride = int(g.choice([1, 1, 2, 3]))
+    x, w = rnd((B, Cin, H, W), 6000 + seed), rnd((Cout, Cin, 1, 1), 6100 + seed) / np.sqrt(Cin)
+    a = ops.conv2d(x, w, stride, 0, "nchw")
+    assert np.array_equal(a, ops.conv2d(x, w, stride, 0, "nhwc")), (B, Cin, Cout, H, W, stride)
+    want = O.conv2d(x, w, stride, 0)
+    assert np.abs(a - want).max() <= 2e-6 * np.sqrt(Cin) * float(np.abs(want).max()) + 1e-6
