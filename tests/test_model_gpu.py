@@ -851,3 +851,27 @@ def test_plain_c_driver_names_the_fixed_geometry(state50, tmp_path):
         r = subprocess.run([exe, "--arch", "50", "--weights", str(wdir), "--input", str(inp), "--batch", "1"] + extra,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "3 x 224 x 224" in r.stderr and "unsupported" in r.stderr, r.stderr
+
+
+def test_sharded_stream_with_idle_shards_and_teardown_in_flight(state50, model50, finch):
+    """A batch smaller than the group leaves shards without images: they stay idle through open /
+    submit / collect and have no staging buffer.  Destroying a group (and a pipeline) with batches
+    still in flight must wait for them, not crash."""
+    x = R.weights.generate_input(2, seed=808)
+    x[1] = finch[0]
+    want = model50.forward(x, fused=True)
+    g = R.ShardedModel([0, 0, 0], "resnet50", state=state50)
+    try:
+        g.stream_open(2, fused=True)
+        bufs = [g.stream_buffer(r) for r in range(3)]
+        assert [b[1:] for b in bufs] == [(0, 1), (1, 2), (2, 2)] and bufs[2][0] is None
+        g.submit(x)
+        logits, top1 = g.collect()
+        assert np.array_equal(logits, want) and int(top1[1]) == 112
+        g.submit(x); g.submit(x)          # left in flight on purpose
+    finally:
+        g.close()
+    pipe = R.Pipeline(model50, 2, fused=True)
+    pipe.submit(x); pipe.submit(x[:1])
+    pipe.close()                          # two batches in flight
+    assert np.array_equal(model50.forward(x, fused=True), want)
