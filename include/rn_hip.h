@@ -478,7 +478,7 @@ RN_API int rn_shard_tune(rn_shard *g, const float *host_input_nchw, uint64_t B, 
 /* Upload, forward and download overlap on every device (main.cu:236-240 and tensor.cuh:184-199
  * do them strictly in sequence, from pageable memory): each device owns an rn_pipeline -- pinned
  * staging, a copy stream, two slots.  rn_shard_forward sends a shard through it in chunks of at
- * most 256 images, two in flight.  The streaming form below keeps two whole BATCHES in flight:
+ * most 128 images, two in flight.  The streaming form below keeps two whole BATCHES in flight:
  *   rn_shard_stream_open(g, B, mode);            shard r owns images rn_shard_bounds(B, r, G)
  *   rn_shard_submit(g, batch0); rn_shard_submit(g, batch1);
  *   rn_shard_collect(g, logits0, top1_0); rn_shard_submit(g, batch2); ...

@@ -756,6 +756,9 @@ def test_sharded_stream_keeps_two_batches_in_flight(state50, model50, finch):
         assert g.in_flight() == 2
         with pytest.raises(R.RnError):
             g.submit(xs[2])                      # both slots busy
+        with pytest.raises(R.RnError) as e:
+            g.forward(xs[3], fused=True)         # the one-shot call is refused while batches are in flight
+        assert "in flight" in str(e.value)
         l0, t0 = g.collect()
         assert np.array_equal(l0, want[0]) and np.array_equal(t0, R.ops.argmax(want[0]))
         # zero-copy: write shard r's images into its pinned staging buffer, submit nothing
@@ -771,13 +774,13 @@ def test_sharded_stream_keeps_two_batches_in_flight(state50, model50, finch):
         with pytest.raises(R.RnError):
             g.collect()                          # nothing in flight
         # the one-shot call still works afterwards (it re-sizes the pipelines), and a shard larger
-        # than the 256-image chunk goes through in several chunks
+        # than the 128-image chunk goes through in several chunks
         l3, t3 = g.forward(xs[3], fused=True)
         assert np.array_equal(l3, want[3]) and np.array_equal(t3, R.ops.argmax(want[3]))
         g.stream_close()
     finally:
         g.close()
-    big = np.concatenate([xs[0]] * 30)[:290]     # one device, 290 images: chunks of 256 + 34
+    big = np.concatenate([xs[0]] * 30)[:290]     # one device, 290 images: chunks of 128 + 128 + 34
     g = R.ShardedModel([0], "resnet50", state=state50)
     try:
         lb, tb = g.forward(big, fused=True)
