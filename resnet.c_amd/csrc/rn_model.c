@@ -1142,13 +1142,42 @@ int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *lo
     return RN_OK;
 }
 
+#define RN_TUNE_ROUNDS 6
+
+/* one recorded contraction call again, on context `run` */
+static int replay_call(rn_model *m, rn_ctx *run, const rn_conv_call *k)
+{
+    rn_conv *cv = &m->convs[k->conv];
+    const uint64_t ho = rn_conv_output_size(k->H, cv->k, cv->stride, k->pad);
+    const uint64_t wo = rn_conv_output_size(k->W, cv->k, cv->stride, k->pad);
+    if (k->pair_block >= 0) {
+        const rn_block *pb = &m->blocks[k->pair_block];
+        const rn_conv *cd = &m->convs[pb->ds];
+        rn_conv_second second;
+        second.inp = k->x2; second.in_channels = cd->cin; second.H = k->H2;
+        second.W = k->W2; second.stride = cd->stride;
+        return rn_conv2d_nhwc_pair_forward_dt(run, m->dtype, m->dtype, k->x, k->y, pb->pair_packed, cv->k,
+                                              cv->stride, k->pad, ho, wo, k->B, cv->cin, cv->cout, k->H,
+                                              k->W, &second, &k->ep);
+    }
+    if (k->exact)
+        return rn_conv2d_nhwc_exact_forward(run, (const float *)k->x, (float *)k->y, m->stem_packed_exact,
+                                            cv->k, cv->stride, ho, wo, k->B, cv->cin, cv->cout, k->H, k->W,
+                                            k->has_ep ? &k->ep : NULL);
+    return rn_conv2d_nhwc_forward_dt(run, m->dtype, m->dtype, k->x, k->y, cv->packed, cv->k, cv->stride,
+                                     k->pad, ho, wo, k->B, cv->cin, cv->cout, k->H, k->W,
+                                     k->has_ep ? &k->ep : NULL);
+}
+
 /* time every tile candidate of every contraction of a forward of B images (one launch batch);
  * the winners go to slot `slot` of the layers' tile tables */
 static int tune_at(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode, int slot)
 {
     rn_event *e0 = NULL, *e1 = NULL;
     const int ncand = rn_conv_tile_candidates();
+    float cand_ms[64];
     int i, c, r, st;
+    if (ncand + 1 > 64) return RN_ERR_INVALID;
     m->single_stream_only = 1;
     /* one recorded forward with the per-launch choice: fills the buffers with real data */
     m->n_calls = 0;
@@ -1162,45 +1191,30 @@ static int tune_at(rn_model *m, const float *input_nchw, uint64_t B, float *logi
     for (i = 0; st == RN_OK && i < m->n_calls; ++i) {
         const rn_conv_call *k = &m->calls[i];
         rn_conv *cv = &m->convs[k->conv];
-        const uint64_t ho = rn_conv_output_size(k->H, cv->k, cv->stride, k->pad);
-        const uint64_t wo = rn_conv_output_size(k->W, cv->k, cv->stride, k->pad);
         float best = 1e30f;
         int best_c = 0, seen = 0, j;
         for (j = 0; j < i; ++j) /* the slices of a depth-first front repeat their calls */
             seen |= m->calls[j].conv == k->conv && m->calls[j].pair_block == k->pair_block &&
                     m->calls[j].B == k->B;
         if (seen) continue;
-        for (c = 0; c <= ncand && st == RN_OK; ++c) { /* 0 = the per-launch choice itself */
-            float ms = 1e30f;
-            rn_ctx_set_conv_tile(m->ctx, c);
-            for (r = 0; r < 4 && st == RN_OK; ++r) {
+        /* repetitions outside, candidates inside: a clock or temperature drift during the
+         * measurement meets every candidate alike (candidate by candidate, the later ones were
+         * timed on a warmer chip); the first round warms the caches and is not counted */
+        for (c = 0; c <= ncand; ++c) cand_ms[c] = 1e30f;
+        for (r = 0; r < RN_TUNE_ROUNDS && st == RN_OK; ++r) {
+            for (c = 0; c <= ncand && st == RN_OK; ++c) { /* 0 = the per-launch choice itself */
                 float t = 0.f;
+                rn_ctx_set_conv_tile(m->ctx, c);
                 st = rn_event_record(m->ctx, e0);
-                if (st == RN_OK && k->pair_block >= 0) {
-                    const rn_block *pb = &m->blocks[k->pair_block];
-                    const rn_conv *cd = &m->convs[pb->ds];
-                    rn_conv_second second;
-                    second.inp = k->x2; second.in_channels = cd->cin; second.H = k->H2;
-                    second.W = k->W2; second.stride = cd->stride;
-                    st = rn_conv2d_nhwc_pair_forward_dt(m->ctx, m->dtype, m->dtype, k->x, k->y,
-                                                        pb->pair_packed, cv->k, cv->stride, k->pad,
-                                                        ho, wo, k->B, cv->cin, cv->cout, k->H, k->W,
-                                                        &second, &k->ep);
-                } else if (st == RN_OK && k->exact) {
-                    st = rn_conv2d_nhwc_exact_forward(m->ctx, (const float *)k->x, (float *)k->y,
-                                                      m->stem_packed_exact, cv->k, cv->stride, ho,
-                                                      wo, k->B, cv->cin, cv->cout, k->H, k->W,
-                                                      k->has_ep ? &k->ep : NULL);
-                } else if (st == RN_OK)
-                    st = rn_conv2d_nhwc_forward_dt(m->ctx, m->dtype, m->dtype, k->x, k->y, cv->packed,
-                                                   cv->k, cv->stride, k->pad, ho, wo, k->B, cv->cin,
-                                                   cv->cout, k->H, k->W, k->has_ep ? &k->ep : NULL);
+                if (st == RN_OK) st = replay_call(m, m->ctx, k);
                 if (st == RN_OK) st = rn_event_record(m->ctx, e1);
                 if (st == RN_OK) st = rn_event_elapsed_ms(e0, e1, &t);
-                if (r > 0 && t < ms) ms = t; /* first repetition warms the caches */
+                if (r > 0 && t < cand_ms[c]) cand_ms[c] = t;
             }
-            if (ms < best * 0.995f) { /* ties keep the earlier (default) candidate */
-                best = ms;
+        }
+        for (c = 0; c <= ncand; ++c) {
+            if (cand_ms[c] < best * 0.995f) { /* ties keep the earlier (default) candidate */
+                best = cand_ms[c];
                 best_c = c;
             }
         }

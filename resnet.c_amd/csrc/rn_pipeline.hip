@@ -198,18 +198,28 @@ int rn_pipeline_submit_n(rn_pipeline *p, const float *host_input_nchw, uint64_t 
     const size_t in_bytes = (size_t)n * 3 * 224 * 224 * sizeof(float);
     if (host_input_nchw && host_input_nchw != s->h_in)
         memcpy(s->h_in, host_input_nchw, in_bytes);  // pageable -> pinned
-    RN_HIP_TRY(ctx, hipMemcpyAsync(s->d_in, s->h_in, in_bytes, hipMemcpyHostToDevice, p->copy_stream));
-    RN_HIP_TRY(ctx, hipEventRecord(s->uploaded, p->copy_stream));
-    // forward on the compute stream once the upload has landed; the other slot's forward may
-    // still be running there, which is exactly the overlap
-    RN_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->uploaded, 0));
-    RN_TRY(rn_model_forward(p->model, s->d_in, n, s->d_out, p->mode));
-    RN_TRY(rn_argmax_forward(ctx, s->d_out, s->d_idx, n, 1000));
-    RN_HIP_TRY(ctx, hipMemcpyAsync(s->h_out, s->d_out, (size_t)n * 1000 * sizeof(float), hipMemcpyDeviceToHost,
-                                   ctx->stream));
-    RN_HIP_TRY(ctx, hipMemcpyAsync(s->h_idx, s->d_idx, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                   ctx->stream));
-    RN_HIP_TRY(ctx, hipEventRecord(s->done, ctx->stream));
+    const int st = [&]() -> int {
+        RN_HIP_TRY(ctx, hipMemcpyAsync(s->d_in, s->h_in, in_bytes, hipMemcpyHostToDevice, p->copy_stream));
+        RN_HIP_TRY(ctx, hipEventRecord(s->uploaded, p->copy_stream));
+        // forward on the compute stream once the upload has landed; the other slot's forward may
+        // still be running there, which is exactly the overlap
+        RN_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s->uploaded, 0));
+        RN_TRY(rn_model_forward(p->model, s->d_in, n, s->d_out, p->mode));
+        RN_TRY(rn_argmax_forward(ctx, s->d_out, s->d_idx, n, 1000));
+        RN_HIP_TRY(ctx, hipMemcpyAsync(s->h_out, s->d_out, (size_t)n * 1000 * sizeof(float), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+        RN_HIP_TRY(ctx, hipMemcpyAsync(s->h_idx, s->d_idx, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+        RN_HIP_TRY(ctx, hipEventRecord(s->done, ctx->stream));
+        return RN_OK;
+    }();
+    if (st != RN_OK) {
+        // the slot stays free, so the next submit writes its staging buffer again: whatever part of
+        // this batch was queued (the upload reads h_in) has to be over before that
+        (void)hipStreamSynchronize(p->copy_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        return st;
+    }
     s->busy = 1;
     s->n = n;
     ++p->head;

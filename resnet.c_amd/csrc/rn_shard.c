@@ -421,12 +421,15 @@ int rn_shard_tune(rn_shard *g, const float *host_input_nchw, uint64_t B, int mod
 /* ---- streaming form: consecutive batches of B images, two in flight per device ---------- */
 int rn_shard_stream_open(rn_shard *g, uint64_t B, int mode)
 {
+    int st;
     if (!g || B == 0) return RN_ERR_INVALID;
     g->numel = B;
     g->ivalue = mode;
     g->stream_B = B;
     g->stream_in_flight = 0;
-    return post(g, JOB_STREAM_OPEN);
+    st = post(g, JOB_STREAM_OPEN);
+    if (st != RN_OK) g->stream_B = 0; /* a device without its pipeline: the stream is not open */
+    return st;
 }
 
 int rn_shard_stream_close(rn_shard *g)

@@ -51,6 +51,9 @@ if [ $what = pmc ] || [ $what = all ]; then
     python3 bench.py --dtype $dt --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-ops-leg > $o/pmc_ref_$dt.json 2> /dev/null
     read n bytes <<< $(python3 -c "import json;r=json.loads(open('$o/pmc_ref_$dt.json').read().strip().splitlines()[-1])['roofline'];print(r['launches_per_forward'], r['bytes_per_forward'])")
     python tools/pmc_traffic.py $o/pmc_${dt}_FETCH_SIZE $o/pmc_${dt}_WRITE_SIZE $o/hbm_traffic_pmc_$dt.json $n $bytes "ResNet-50 $dt B=256 fused; separate --pmc passes; FETCH_SIZE x2" > /dev/null
+    # the same bytes launch by launch next to each layer's algorithmic bytes (where an excess sits)
+    python tools/layer_report.py --tune --dtype $dt > $o/pmc_layers_$dt.txt 2> /dev/null
+    python tools/pmc_per_layer.py $o/pmc_${dt}_FETCH_SIZE $o/pmc_${dt}_WRITE_SIZE $o/pmc_layers_$dt.txt $n > $o/hbm_traffic_pmc_$dt.per_layer.txt
   done
   # the same two passes for ResNet-152 fp32 B=128 (configs[4])
   for c in FETCH_SIZE WRITE_SIZE; do

@@ -11,13 +11,14 @@ import resnet_c_amd as R
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--route-only", action="store_true", help="only the NCHW op-by-op route, asynchronous (for a kernel trace)")
 a = ap.parse_args()
 state = R.weights.generate_state("resnet50", 0)
 x_host = R.weights.generate_input(a.batch, 0)
 ctx = R.get_ctx()
 x = R.FloatTensor.from_numpy(x_host, R.Device.GPU)
 m = R.createResnet("resnet50", state)
-for sync, cache in ((True, False), (False, False), (False, True)):
+for sync, cache in (((False, False),) if a.route_only else ((True, False), (False, False), (False, True))):
     ctx.set_sync_each_op(sync)
     ctx.set_weight_cache(cache)
     for _ in range(2):
@@ -30,6 +31,8 @@ for sync, cache in ((True, False), (False, False), (False, True)):
     dt = (time.perf_counter() - t0) / a.steps
     print(f"NCHW op-by-op graph, sync after each op = {sync}, packed-weight cache = {cache}: "
           f"{dt*1e3:8.2f} ms/forward  {a.batch/dt:8.1f} img/s")
+if a.route_only:
+    sys.exit(0)
 ctx.set_sync_each_op(False)
 ctx.set_weight_cache(False)
 nm = R.NativeModel("resnet50", state=state)
