@@ -950,7 +950,7 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
         } else if (ctx->conv_tile == 0 && p.nk >= 8 && Cout >= 128) {
             // relative efficiency of a full tile (the 64x64 wave tiles of the 128-wide forms
             // read twice the LDS bytes per MFMA)
-            static const double eff_wide[5] = {1.00, 0.80, 0.80, 0.50, 0.90};
+            static const double eff_wide[6] = {1.00, 0.80, 0.80, 0.50, 0.90, 0.55};
             double best = 1e300;
             for (int wi = 0; wi < nwide; ++wi) {
                 int bm, bn;

@@ -105,7 +105,7 @@ inline void rn_fast_div(unsigned d, unsigned *mul, unsigned *shr)
 }
 
 // bf16 contraction on 256-wide block tiles (rn_conv_wide.hip).  which: 0 = 256x256, 1 = 256x128,
-// 2 = 128x256, 3 = 256x64, 4 = 224x256.  Caller has checked rn_conv_wide_eligible().
+// 2 = 128x256, 3 = 256x64, 4 = 224x256, 5 = 128x128 (two blocks per CU).  Caller has checked rn_conv_wide_eligible().
 int rn_conv_wide_count(void);
 bool rn_conv_wide_eligible(const rn_gemm::GemmParams &p, int which);
 void rn_conv_wide_tile(int which, int *bm, int *bn);

@@ -62,9 +62,13 @@ struct Out<bf16_t> {
     }
 };
 
-// BM x BN block tile, WM x WN waves (WM * WN == 8), DUAL as in conv_gemm_kernel
-template <typename TO, int BM, int BN, int WM, int WN, bool DUAL>
-__global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
+// BM x BN block tile, WM x WN waves (WM * WN == 8), DUAL as in conv_gemm_kernel.
+// LDS_CAP: the block's LDS budget.  All of the CU's 160 KB for the 256-wide tiles (one block per CU);
+// 80 KB for the 128x128 tile, so that TWO blocks share a CU (four waves per SIMD, 128 registers each)
+// and one's prologue and epilogue run beside the other's K loop -- the short-K and memory-paced 1x1
+// layers of stage 3-4, where a lone block's fill and drain are a third of its life.
+template <typename TO, int BM, int BN, int WM, int WN, bool DUAL, int LDS_CAP = 160 * 1024>
+__global__ __launch_bounds__(512, LDS_CAP <= 80 * 1024 ? 4 : 2) void conv_wide_kernel(const GemmParams p)
 {
     static_assert(WM * WN == 8, "eight waves");
     constexpr int TM = BM / WM, TN = BN / WN;  // wave tile
@@ -77,9 +81,9 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
     static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile in whole fragments");
     constexpr int A_SLOT = AM * 128, B_SLOT = BN * 128;  // bytes of one K tile of A / of B
     constexpr int SA = 3;
-    constexpr int SB = 3 * (A_SLOT + B_SLOT) <= 160 * 1024 ? 3 : 2;
+    constexpr int SB = 3 * (A_SLOT + B_SLOT) <= LDS_CAP ? 3 : 2;
     constexpr int LDS_BYTES = SA * A_SLOT + SB * B_SLOT;
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(LDS_BYTES <= LDS_CAP, "LDS");
     // epilogue staging: the fp32 tile in one pass, or its two halves of BM/2 rows
     constexpr int CPASS = AM * BN * 4 <= LDS_BYTES ? 1 : 2;
     constexpr int EROWS = AM / CPASS;
@@ -419,16 +423,16 @@ __global__ __launch_bounds__(512, 2) void conv_wide_kernel(const GemmParams p)
 struct WideTile {
     int bm, bn;
 };
-constexpr WideTile kTiles[] = {{256, 256}, {256, 128}, {128, 256}, {256, 64}, {224, 256}};
+constexpr WideTile kTiles[] = {{256, 256}, {256, 128}, {128, 256}, {256, 64}, {224, 256}, {128, 128}};
 constexpr int kNumTiles = (int)(sizeof(kTiles) / sizeof(kTiles[0]));
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int LDS_CAP = 160 * 1024>
 void launch(rn_ctx *ctx, const GemmParams &p, bool dual)
 {
     if (dual)
-        conv_wide_kernel<bf16_t, BM, BN, WM, WN, true><<<dim3(p.total_tiles), dim3(512), 0, ctx->stream>>>(p);
+        conv_wide_kernel<bf16_t, BM, BN, WM, WN, true, LDS_CAP><<<dim3(p.total_tiles), dim3(512), 0, ctx->stream>>>(p);
     else
-        conv_wide_kernel<bf16_t, BM, BN, WM, WN, false><<<dim3(p.total_tiles), dim3(512), 0, ctx->stream>>>(p);
+        conv_wide_kernel<bf16_t, BM, BN, WM, WN, false, LDS_CAP><<<dim3(p.total_tiles), dim3(512), 0, ctx->stream>>>(p);
 }
 
 
@@ -908,7 +912,8 @@ void rn_conv_wide_launch(rn_ctx *ctx, GemmParams &p, int which, bool dual)
     case 1: launch<256, 128, 4, 2>(ctx, p, dual); break;
     case 2: launch<128, 256, 2, 4>(ctx, p, dual); break;
     case 3: launch<256, 64, 8, 1>(ctx, p, dual); break;
-    default: launch<224, 256, 1, 8>(ctx, p, dual); break;
+    case 4: launch<224, 256, 1, 8>(ctx, p, dual); break;
+    default: launch<128, 128, 2, 4, 80 * 1024>(ctx, p, dual); break;
     }
 }
 

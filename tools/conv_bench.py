@@ -65,7 +65,7 @@ def main():
                                                   Cout, H, W, ctypes.byref(ep)), "conv", ctx.handle)
     ctx.sync()
     names = ["auto", "128x128", "128x64", "64x128", "64x64", "P128x128", "P128x64", "P64x128", "P64x64",
-             "W256x256", "W256x128", "W128x256", "W256x64", "W224x256", "strip"]
+             "W256x256", "W256x128", "W128x256", "W256x64", "W224x256", "W128x128", "strip"]
     for cand in (range(0, lib.rn_conv_tile_candidates() + 1) if a.cand < 0 else [a.cand]):
         lib.rn_ctx_set_conv_tile(ctx.handle, cand)
         def run():

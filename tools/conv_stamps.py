@@ -4,7 +4,7 @@
     python tools/conv_stamps.py B H W Cin Cout k stride pad --cand 1 [--dtype bf16] [--residual]
 Stamps (100 MHz): 0 block start, 1 first operands staged, 2 K loop done, 3 epilogue stores
 issued, 4 stores acknowledged.  Prints medians in microseconds over all blocks.
---raw: every slot relative to slot 0 (conv_strip_kernel, candidate 14: 0 start, 1 first barrier
+--raw: every slot relative to slot 0 (conv_strip_kernel, candidate 15: 0 start, 1 first barrier
 passed, 2-6 step 4: top / own memory landed / barrier passed / taps done / results packed, 7 end of
 step 5, 10 last step done, 11 stores acknowledged)."""
 import argparse, ctypes, os, sys
