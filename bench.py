@@ -283,7 +283,7 @@ def main():
     model = R.NativeModel(args.arch, state=state, ctx=ctx, dtype=args.dtype)
     if args.streams:
         model.set_streams(args.streams)
-    args.streams = model.streams()
+    args.streams = model.parts(B)  # what a forward of B images runs as (library default: by dtype and B)
     model.set_front_parts(args.front_parts)
     lo, hi = shard_bounds(world * B, rank, world)
     # this rank's shard of the global batch: image i depends on (seed, i) only

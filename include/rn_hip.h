@@ -297,11 +297,15 @@ RN_API int rn_model_set_stem_exact(rn_model *m, int on);
  * each) on streams of their own -- the launches of one part fill the tails of the others';
  * every image's logits are independent of what else is in its launch, so no bit changes.
  * Default: 2 (measured at B = 256: fp32 +0.8 %, bf16 storage +5..9 %: its 256-wide tiles leave
- * CUs idle in the late stages).  Profiled and tuning forwards always use one stream.  Tuned tiles
+ * CUs idle in the late stages); as long as this function has not been called, an fp32 model splits
+ * only into parts of at least 128 images (parts of 96 measured 3 % slower than one stream, parts
+ * of 64 equal).  Profiled and tuning forwards always use one stream.  Tuned tiles
  * are kept per launch batch size (rn_model_tune times the parts' size and the whole batch), so
  * switching between the tuned part count and one stream keeps them. */
 RN_API int rn_model_set_streams(rn_model *m, int streams);
 RN_API int rn_model_get_streams(const rn_model *m);
+/* the number of parts (streams) a forward of B images actually runs as under the rule above */
+RN_API int rn_model_parts(const rn_model *m, uint64_t B);
 /* parts = 1 (default), 2, 4, 8 or 16: the stem, the max-pool and the first stage -- the layers
  * with the largest tensors -- run in that many slices of each batch part, one after the other,
  * so that what one kernel writes is still in the 256 MB Infinity Cache when the next reads it;

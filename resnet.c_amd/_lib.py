@@ -111,6 +111,7 @@ SIGNATURES = {
     "rn_model_set_stem_pool_fusion": (c_int, [c_void_p, c_int]),
     "rn_model_set_streams": (c_int, [c_void_p, c_int]),
     "rn_model_get_streams": (c_int, [c_void_p]),
+    "rn_model_parts": (c_int, [c_void_p, u64]),
     "rn_model_set_front_parts": (c_int, [c_void_p, c_int]),
     "rn_maxpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),
     "rn_avgpool2d_nhwc_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr] + [u64] * 9),

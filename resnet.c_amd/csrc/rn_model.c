@@ -112,7 +112,7 @@ struct rn_model {
      * round of tiles, prologues, epilogues) of the other's.  Every image's logits are
      * independent of what else is in its launch, so the split changes no bit.  The second
      * stream belongs to a second context on the same device (own scratch). */
-    int streams;            /* parts a sub-batch is split into (each >= RN_STREAM_MIN_PART images) */
+    int streams;            /* parts a sub-batch is split into (each >= RN_STREAM_MIN_PART(m) images) */
     rn_ctx *ctxn[RN_MAX_STREAMS - 1];     /* contexts of parts 1.. (part 0 runs on ctx) */
     rn_event *ev_fork, *ev_join[RN_MAX_STREAMS - 1];
     int streams_set;        /* rn_model_set_streams was called: keep it whatever the dtype */
@@ -555,6 +555,9 @@ int rn_model_set_streams(rn_model *m, int streams)
 }
 
 int rn_model_get_streams(const rn_model *m) { return m ? m->streams : 0; }
+
+static int parts_of(const rn_model *m, uint64_t B);
+int rn_model_parts(const rn_model *m, uint64_t B) { return m && B ? parts_of(m, B) : 0; }
 
 int rn_model_set_stem_pool_fusion(rn_model *m, int on)
 {
@@ -1066,7 +1069,23 @@ static int forward_sub(rn_model *m, rn_ctx *run, uint64_t img_off, const float *
     return st;
 }
 
-#define RN_STREAM_MIN_PART 64
+/* smallest batch part worth a stream of its own.  bf16 launches are short (fill and drain are a
+ * third of their life): parts of 64 still gain 6-8 %.  fp32 launches are matrix-bound rounds of
+ * tiles: parts of 128 gain 1 %, parts of 96 LOSE 3 % (B = 192), parts of 64 nothing
+ * (tools/streams_ab.sh) -- so the library's own default of two streams starts at parts of 128 there;
+ * a count the caller set (rn_model_set_streams) is taken down to parts of 64 */
+#define RN_STREAM_MIN_PART(m) ((m)->dtype == RN_DTYPE_F32 && !(m)->streams_set ? 128u : 64u)
+
+#define RN_MAX_SUB_BATCH 512 /* images per launch batch: see rn_model_forward */
+
+/* parts (streams) a launch batch of B images runs as */
+static int parts_of(const rn_model *m, uint64_t B)
+{
+    int parts = m->streams;
+    if (B > RN_MAX_SUB_BATCH) B = RN_MAX_SUB_BATCH;
+    while (parts > 1 && B / (uint64_t)parts < RN_STREAM_MIN_PART(m)) parts /= 2;
+    return parts;
+}
 #define RN_FRONT_MIN_SLICE 16
 
 /* B images at image offset img_off on `run`: whole, or depth-first through the front */
@@ -1091,10 +1110,9 @@ static int forward_part(rn_model *m, rn_ctx *run, uint64_t img_off, const float 
 static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
 {
     uint64_t lo = 0;
-    int parts = m->streams, i;
+    int parts = parts_of(m, B), i;
     TRY(ensure_acts(m, B));
     m->n_prof = 0;
-    while (parts > 1 && B / (uint64_t)parts < RN_STREAM_MIN_PART) parts /= 2;
     if (parts < 2 || m->profiling || m->single_stream_only || m->recording)
         return forward_part(m, m->ctx, 0, input_nchw, B, logits, mode);
     if (!m->ev_fork) TRY(rn_event_create(m->ctx, &m->ev_fork));
@@ -1123,8 +1141,8 @@ static int forward_chunk(rn_model *m, const float *input_nchw, uint64_t B, float
  * kernels address every tensor with 32-bit byte offsets (2^29 fp32 elements; the stem output
  * of 669 images is the first to pass it), so a larger batch runs as sub-batches of at most
  * RN_MAX_SUB_BATCH images through the same arenas.  Every image's logits are independent of
- * what else is in its launch (batch invariance, bit for bit), so the split changes nothing. */
-#define RN_MAX_SUB_BATCH 512
+ * what else is in its launch (batch invariance, bit for bit), so the split changes nothing.
+ * (RN_MAX_SUB_BATCH is defined above, next to the stream split.) */
 
 int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode)
 {
@@ -1241,8 +1259,7 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
     if (B > RN_MAX_SUB_BATCH) B = RN_MAX_SUB_BATCH; /* the launches of a larger batch are sub-batches */
     Bp = B;
     {   /* ... and those run as `streams` parts */
-        int parts = m->streams;
-        while (parts > 1 && B / (uint64_t)parts < RN_STREAM_MIN_PART) parts /= 2;
+        const int parts = parts_of(m, B);
         if (parts > 1) Bp = B / (uint64_t)parts;
     }
     m->tuned_B = 0;

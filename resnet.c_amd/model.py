@@ -267,11 +267,17 @@ class NativeModel:
         L.check(L.lib().rn_model_set_pair_fusion(self.handle, int(on)), "rn_model_set_pair_fusion")
 
     def set_streams(self, streams: int) -> None:
-        """2 (default): batches of >= 128 images run as two halves on two streams; 1: one stream."""
+        """2 (default): batches of >= 128 images (fp32 at the default: >= 256) run as two halves on two
+        streams; 1: one stream."""
         L.check(L.lib().rn_model_set_streams(self.handle, int(streams)), "rn_model_set_streams")
 
     def streams(self) -> int:
         return int(L.lib().rn_model_get_streams(self.handle))
+
+    def parts(self, B: int) -> int:
+        """Streams a forward of B images actually runs on: the configured count, halved while a part
+        would be smaller than 64 images (128 for an fp32 model left at the library default)."""
+        return int(L.lib().rn_model_parts(self.handle, int(B)))
 
     def set_chain(self, on: bool) -> None:
         """Fused mode: conv3 of a bottleneck block + conv1 of the next block as one launch wherever

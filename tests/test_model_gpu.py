@@ -426,6 +426,33 @@ def test_chains_in_the_deeper_networks(arch, dtype):
         m.close()
 
 
+def test_default_stream_split_by_dtype_and_batch(state50):
+    """The library's own default of two streams starts where it was measured to pay: parts of 128
+    images in fp32 (parts of 96 measured 3 % slower than one stream), parts of 64 with bf16 storage;
+    a count the caller sets is taken down to parts of 64 in both.  rn_model_parts says what a forward
+    of B images runs as; the bits never depend on it."""
+    m = R.NativeModel("resnet50", state=state50)
+    try:
+        assert m.streams() == 2
+        assert [m.parts(B) for B in (1, 64, 128, 192, 255, 256, 512, 2048)] == [1, 1, 1, 1, 1, 2, 2, 2]
+        x = R.weights.generate_input(128, seed=5)
+        base = m.forward(x, fused=True)          # one stream under the default
+        m.set_streams(2)
+        assert [m.parts(B) for B in (64, 127, 128, 192, 256)] == [1, 1, 2, 2, 2]
+        assert np.array_equal(m.forward(x, fused=True), base)
+        m.set_streams(4)
+        assert [m.parts(B) for B in (128, 255, 256)] == [2, 2, 4]
+        m.set_streams(1)
+        assert m.parts(2048) == 1
+    finally:
+        m.close()
+    m = R.NativeModel("resnet50", state=state50, dtype="bf16")
+    try:
+        assert [m.parts(B) for B in (64, 127, 128, 192, 256)] == [1, 1, 2, 2, 2]
+    finally:
+        m.close()
+
+
 def test_two_stream_forward_under_capture_pipeline_and_shards(state50, finch):
     """bf16 models run a batch of >= 128 images as two halves on two streams (fork / join events).
     The same forward captured as a hipGraph (a cross-stream capture), fed through the host
