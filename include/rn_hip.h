@@ -381,7 +381,9 @@ RN_API int rn_conv_chain_pair_forward_dt(rn_ctx *ctx, int dtype, const void *t2,
                                          const float *shift1, uint64_t rows, uint64_t mid_channels,
                                          uint64_t in2_channels, uint64_t channels, uint64_t next_mid);
 /* Fused mode: conv3 of a block and conv1 of the block after it as one launch where a chain kernel
- * exists (rn_conv_chain_forward_dt; default on).  The same bits either way. */
+ * exists (rn_conv_chain_forward_dt; default on = 1).  2: also the 256-channel blocks of stage 3 with
+ * bf16 storage, whose chain kernel streams both weight panels through LDS and is SLOWER than its two
+ * launches (kept for measurement).  The same bits whatever the setting. */
 RN_API int rn_model_set_chain(rn_model *m, int on);
 /* Fused mode: use it for conv1 + bn1 + relu + maxpool (default on; fp32 needs the exact-K stem
  * image, rn_model_set_stem_exact).  on == 2: through rn_stem_pool_nchw_forward_dt, the input

@@ -128,4 +128,10 @@ bool rn_conv1x1_nchw_eligible(uint64_t kernel_size, uint64_t stride, uint64_t pa
 int rn_conv1x1_nchw_launch(rn_ctx *ctx, const float *inp, float *out, const float *weight, uint64_t stride,
                            uint64_t B, uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W);
 
+// rn_chain_wide.hip: conv3 (256 -> 1024, residual) + next conv1 (1024 -> 256) of the stage-3 blocks, bf16;
+// the caller has checked alignment, aliasing and the shapes
+int rn_chain_wide_launch(rn_ctx *ctx, const void *t2, const void *x, void *y, const void *w3, const float *sc3,
+                         const float *sh3, void *t1, const void *w1, const float *sc1, const float *sh1,
+                         uint64_t rows);
+
 #endif

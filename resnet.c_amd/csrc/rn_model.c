@@ -570,7 +570,7 @@ int rn_model_set_stem_pool_fusion(rn_model *m, int on)
 int rn_model_set_chain(rn_model *m, int on)
 {
     if (!m) return RN_ERR_INVALID;
-    m->chain = on ? 1 : 0;
+    m->chain = on < 0 ? 0 : on > 2 ? 2 : on; /* 2: also the streamed-panel chain of stage 3 (slower than its two launches) */
     return RN_OK;
 }
 
@@ -787,7 +787,13 @@ static int chain_applies(const rn_model *m, const rn_block *b, int mode)
     n1 = &m->convs[m->blocks[bi + 1].conv1];
     if (c3->k != 1 || c3->stride != 1 || n1->k != 1 || n1->stride != 1 || n1->cin != c3->cout) return 0;
     if (c3->cin == 64 && c3->cout == 256) return n1->cout == 64 || n1->cout == 128;
-    return m->dtype == RN_DTYPE_BF16 && c3->cin == 128 && c3->cout == 512 && n1->cout == 128 && b->ds < 0;
+    if (m->dtype != RN_DTYPE_BF16 || b->ds >= 0) return 0;
+    /* bf16: the 128-channel blocks of stage 2 (panels in registers); the 256-channel blocks of stage 3
+     * have a chain kernel too (panels streamed through LDS, rn_chain_wide.hip), but it measures 112 us
+     * against 91-95 for its two launches (the 64-KB ring holds less than one fetch latency of weights):
+     * only on request (rn_model_set_chain(m, 2)) */
+    return (c3->cin == 128 && c3->cout == 512 && n1->cout == 128) ||
+           (m->chain >= 2 && c3->cin == 256 && c3->cout == 1024 && n1->cout == 256);
 }
 
 static int op_chain(rn_model *m, const rn_block *b, const void *t2, const void *shortcut, void *y,

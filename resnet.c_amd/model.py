@@ -282,8 +282,9 @@ class NativeModel:
     def set_chain(self, on: bool) -> None:
         """Fused mode: conv3 of a bottleneck block + conv1 of the next block as one launch wherever
         a chain kernel exists (fp32: the 64-channel blocks of stage 1; bf16: those and the
-        128-channel blocks of stage 2; rn_model.c chain_applies).  Default on; the same bits
-        either way."""
+        128-channel blocks of stage 2; rn_model.c chain_applies).  Default on; 2 also chains the
+        256-channel blocks of stage 3 (bf16; measured slower than their two launches).  The same bits
+        whatever the setting."""
         L.check(L.lib().rn_model_set_chain(self.handle, int(on)), "rn_model_set_chain")
 
     def set_stem_pool_fusion(self, on) -> None:

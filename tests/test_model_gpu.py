@@ -361,7 +361,8 @@ def test_chained_conv3_conv1_changes_launches_not_results(state50, finch):
     """bf16 fused mode: conv3 of the 64-channel blocks and conv1 of the block after them as one launch
     (rn_conv_chain_forward_dt, default on) against the separate launches: five ops fewer in
     ResNet-50 (layer1.0's fused conv3 + downsample pair -> 1.1, layer1.1 -> 1.2, layer1.2 -> layer2.0,
-    layer2.1 -> 2.2, layer2.2 -> 2.3), the same logits bit for bit, also with two streams and in sub-batches."""
+    layer2.1 -> 2.2, layer2.2 -> 2.3), nine with the opt-in stage-3 chain (layer3.1 -> 3.2 ... 3.4 -> 3.5),
+    the same logits bit for bit, also with two streams and in sub-batches."""
     m = R.NativeModel("resnet50", state=state50, dtype="bf16")
     try:
         x = np.concatenate([finch, R.weights.generate_input(130, seed=61)])
@@ -379,6 +380,14 @@ def test_chained_conv3_conv1_changes_launches_not_results(state50, finch):
                              "layer1.2.conv3+next.conv1", "layer2.1.conv3+next.conv1",
                              "layer2.2.conv3+next.conv1"]
         assert len(ops_plain) == len(ops_chained) + 5
+        # level 2: also the 256-channel blocks of stage 3 (weight panels streamed through LDS)
+        m.set_chain(2)
+        m.set_profiling(True)
+        deep = m.forward(x, fused=True)
+        ops_deep = [l for o, l in ((r["op"], r["layer"]) for r in m.profile()) if o == "conv2d+epilogue+conv2d"]
+        m.set_profiling(False)
+        assert np.array_equal(deep, plain)
+        assert ops_deep == fused_ops + [f"layer3.{i}.conv3+next.conv1" for i in (1, 2, 3, 4)]
         m.set_chain(True)
         m.set_streams(2)
         assert np.array_equal(m.forward(x, fused=True), plain)
