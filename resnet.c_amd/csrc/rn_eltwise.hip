@@ -177,6 +177,43 @@ __global__ __launch_bounds__(kBlock) void bn_nchw_plane_kernel(const float *inp,
     }
 }
 
+// NCHW, small planes (14x14, 7x7): with one wave per plane the square root and the division of
+// bn_derive stand in front of one or two loads per lane (7x7: 2.1-2.5 TB/s).  Here a lane keeps ONE
+// position of the C x N image -- channel (position / N), the same in every image -- derives that
+// channel's constants once and walks the batch: image b's element is b * C * N further, a wave's
+// 64 lanes are 64 consecutive floats (VEC: float4s; a float4 never straddles a plane when N % 4 == 0)
+// of every image.  blockIdx.y splits the batch so that the grid fills the chip.
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void bn_nchw_batchwalk_kernel(const float *inp, float *out, uint32_t per_image,
+                                                                   uint32_t N, uint32_t B, uint32_t b_per_block,
+                                                                   const float *weight, const float *bias,
+                                                                   const float *mean, const float *var)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;  // position in the image, in floats or float4s
+    if (i >= per_image) return;
+    const uint32_t b0 = blockIdx.y * b_per_block, b1 = min(B, b0 + b_per_block);
+    const BnParams p = bn_derive(weight, bias, mean, var, (VEC ? 4 * i : i) / N);
+    if constexpr (VEC) {
+        const f32x4 *in4 = reinterpret_cast<const f32x4 *>(inp) + i;
+        f32x4 *out4 = reinterpret_cast<f32x4 *>(out) + i;
+#pragma unroll 4
+        for (uint32_t b = b0; b < b1; ++b) {
+            f32x4 v = __builtin_nontemporal_load(&in4[(uint64_t)b * per_image]);
+            v.x = bn_apply_reg(v.x, p);
+            v.y = bn_apply_reg(v.y, p);
+            v.z = bn_apply_reg(v.z, p);
+            v.w = bn_apply_reg(v.w, p);
+            __builtin_nontemporal_store(v, &out4[(uint64_t)b * per_image]);
+        }
+    } else {
+#pragma unroll 4
+        for (uint32_t b = b0; b < b1; ++b) {
+            const uint64_t at = (uint64_t)b * per_image + i;
+            out[at] = bn_apply_reg(inp[at], p);
+        }
+    }
+}
+
 // NHWC, C % 4 == 0: a float4 covers channels c4*4 .. c4*4+3 of one pixel.  When the grid
 // stride is a multiple of C/4 every thread keeps the same four channels for its whole
 // walk, so their parameters are loaded once into registers (kFixed); reloading 20
@@ -342,6 +379,23 @@ int rn_batchnorm2d_forward(rn_ctx *ctx, const float *inp, float *out, const floa
             bn_nhwc_vec_kernel<false><<<grid, kBlock, 0, ctx->stream>>>(inp, out, params, total4, c4n,
                                                                         weight, bias, mean, var);
         }
+    } else if (ctx->layout == RN_LAYOUT_NCHW && N <= 256 && B >= 8 && C * N < (1ull << 31)) {
+        // small planes, a batch to walk: one position of the image per lane (see the kernel)
+        const bool vec = al && N % 4 == 0;
+        const uint32_t per_image = (uint32_t)(vec ? C * N / 4 : C * N);
+        const unsigned gx = (unsigned)rn_ceil_div(per_image, kBlock);
+        // about 2,048 blocks (8 per CU), at least 4 images per block
+        uint64_t gy = rn_ceil_div(2048, gx);
+        if (gy > B / 4) gy = B / 4;
+        if (gy < 1) gy = 1;
+        const uint32_t bpb = (uint32_t)rn_ceil_div(B, gy);
+        const dim3 grid(gx, (unsigned)rn_ceil_div(B, bpb));
+        if (vec)
+            bn_nchw_batchwalk_kernel<true><<<grid, kBlock, 0, ctx->stream>>>(inp, out, per_image, (uint32_t)N, (uint32_t)B,
+                                                                             bpb, weight, bias, mean, var);
+        else
+            bn_nchw_batchwalk_kernel<false><<<grid, kBlock, 0, ctx->stream>>>(inp, out, per_image, (uint32_t)N, (uint32_t)B,
+                                                                              bpb, weight, bias, mean, var);
     } else if (ctx->layout == RN_LAYOUT_NCHW && al && N % 4 == 0 && B * C < (1ull << 32)) {
         const uint64_t planes = B * C;
         const unsigned grid = rn_stream_grid(planes * 64, kBlock);

@@ -221,7 +221,9 @@ def test_maxpool_all_padding_window_and_nan():
 
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])
 @pytest.mark.parametrize("shape", [(2, 64, 56, 56), (3, 7, 5, 5), (1, 256, 14, 14), (2, 5, 4, 6), (4, 8, 1, 1),
-                                   (3, 2048, 7, 7), (70, 5, 9, 9)])
+                                   (3, 2048, 7, 7), (70, 5, 9, 9),
+                                   # NCHW, small planes and a batch to walk (one image position per lane):
+                                   (16, 512, 7, 7), (9, 256, 14, 14), (8, 3, 16, 16), (12, 7, 2, 2), (64, 33, 3, 4)])
 def test_batchnorm_matches_double_expression(shape, layout):
     g = np.random.default_rng(sum(shape))
     x = g.standard_normal(shape, dtype=np.float32) * 3
