@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_nchw_kernel(const NchwParams p
 #pragma unroll
     for (int i = 0; i < (GATHER ? 4 : 1); ++i) {
         const unsigned q = q0 + 4u * (unsigned)xq + (unsigned)i;
-        const unsigned b = __umulhi(q, p.mul_hw) >> p.shr_hw;
+        const unsigned b = p.HW == 1 ? q : __umulhi(q, p.mul_hw) >> p.shr_hw;  // (rn_fast_div leaves d = 1 to the kernel)
         unsigned pp = q - b * (unsigned)p.HW;
         if constexpr (GATHER) {  // output pixel -> input pixel
             const unsigned oh = p.Wo == 1 ? pp : __umulhi(pp, p.mul_wo) >> p.shr_wo, ow = pp - oh * (unsigned)p.Wo;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_nchw_kernel(const NchwParams p
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const unsigned q = q0 + (unsigned)(wn * 64 + ni * 32 + li);
-        const unsigned b = __umulhi(q, p.mul_hw) >> p.shr_hw, pp = q - b * (unsigned)p.HW;
+        const unsigned b = p.HW == 1 ? q : __umulhi(q, p.mul_hw) >> p.shr_hw, pp = q - b * (unsigned)p.HW;
         const unsigned obase = b * (unsigned)p.Cout * (unsigned)p.HW + pp;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)

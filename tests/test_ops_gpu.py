@@ -601,7 +601,10 @@ def test_one_thread_two_contexts_interleaved():
                                   (3, 2048, 512, 7, 7, 1, 1, 0),     # 7x7 planes, chunked (layer4's conv1)
                                   (2, 64, 128, 8, 8, 1, 2, 0),       # stride 2 (the projection shortcuts)
                                   (3, 256, 72, 9, 7, 1, 2, 0),       # stride 2 on odd sizes
-                                  (2, 48, 64, 8, 8, 1, 1, 0)])       # Cin not a multiple of 32: the direct kernel, another order
+                                  (2, 48, 64, 8, 8, 1, 1, 0),        # Cin not a multiple of 32: the direct kernel, another order
+                                  (2, 32, 256, 1, 3, 1, 3, 0),       # ONE output pixel per image (found by tools/conv_fuzz.py:
+                                  (5, 64, 40, 1, 1, 1, 1, 0),        #  the q / HW multiply-high has no form for HW = 1)
+                                  (3, 96, 64, 5, 1, 1, 1, 0)])       # one-pixel-wide planes
 def test_nchw_route_writes_the_nhwc_routes_bits(case):
     """rn_conv2d_forward on NCHW tensors: a 1x1 / padding-0 convolution runs on the NCHW-native
     kernel (rn_conv_nchw.hip: weights = MFMA rows, pixels = columns, no transpose, no packing);

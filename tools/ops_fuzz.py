@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomised parity run of the element-wise, pooling, batch-norm and linear entry points against the
+CPU oracle, both layouts (test infrastructure, like tests/).
+
+    python tools/ops_fuzz.py [--seconds 60] [--seed 0]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from oracle import oracle as O
+from resnet_c_amd import ops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    g = np.random.default_rng(a.seed)
+    t0, n = time.time(), {"maxpool": 0, "avgpool": 0, "batchnorm": 0, "linear": 0, "relu/add": 0}
+    while time.time() - t0 < a.seconds:
+        what = str(g.choice(list(n)))
+        layout = str(g.choice(["nchw", "nhwc"]))
+        if what in ("maxpool", "avgpool"):
+            k = int(g.choice([1, 2, 3, 3, 7]))
+            s = int(g.choice([1, 2, 3, 7]))
+            p = int(g.integers(0, k // 2 + 1))
+            B, C = int(g.integers(1, 9)), int(g.choice([1, 3, 4, 8, 12, 64, 100, 256, 2048]))
+            H, W = int(g.integers(max(1, k - 2 * p), 20)), int(g.integers(max(1, k - 2 * p), 20))
+            if C >= 256:
+                H, W = min(H, 8), min(W, 8)
+            if what == "avgpool" and g.random() < 0.4:  # the global pool of the network's tail
+                H = W = k = 7
+                s, p = int(g.choice([1, 7])), 0
+            x = g.standard_normal((B, C, H, W), dtype=np.float32)
+            got = (ops.maxpool2d if what == "maxpool" else ops.avgpool2d)(x, k, s, p, layout)
+            want = (O.maxpool2d if what == "maxpool" else O.avgpool2d)(x, k, s, p)
+            assert np.array_equal(got, want), f"{what} {layout} {x.shape} k={k} s={s} p={p}"
+        elif what == "batchnorm":
+            B, C = int(g.integers(1, 40)), int(g.choice([1, 2, 3, 4, 5, 8, 33, 64, 70, 256]))
+            H, W = int(g.integers(1, 20)), int(g.integers(1, 20))
+            x = g.standard_normal((B, C, H, W), dtype=np.float32) * 3
+            w, b = g.random(C, dtype=np.float32) + 0.5, g.standard_normal(C, dtype=np.float32)
+            m, v = g.standard_normal(C, dtype=np.float32), g.random(C, dtype=np.float32) + 0.5
+            want = O.batchnorm2d(x, w, b, m, v)
+            got = ops.batchnorm2d(x, w, b, m, v, layout, inplace=bool(g.integers(0, 2)))
+            ulp = np.spacing(np.abs(want).astype(np.float32))
+            assert (np.abs(got - want) <= ulp).all(), f"batchnorm {layout} {x.shape}"
+        elif what == "linear":
+            B, I, Oo = int(g.integers(1, 70)), int(g.choice([1, 7, 32, 64, 96, 300, 2048])), int(g.integers(1, 130))
+            x, w = g.standard_normal((B, I), dtype=np.float32), g.standard_normal((Oo, I), dtype=np.float32) / np.sqrt(I)
+            b = g.standard_normal(Oo, dtype=np.float32) if g.random() < 0.7 else None
+            want = O.linear(x, w, b)
+            got = ops.linear(x, w, b)
+            tol = 3e-7 * np.sqrt(I) * (float(np.abs(want).max()) + 1e-6) + 1e-6
+            assert got.shape == want.shape and float(np.abs(got - want).max()) <= tol, f"linear {B}x{I}->{Oo}"
+        else:
+            nel = int(g.choice([1, 3, 4, 5, 63, 64, 1000, 4097, 70001]))
+            x, y = g.standard_normal(nel, dtype=np.float32), g.standard_normal(nel, dtype=np.float32)
+            inplace = bool(g.integers(0, 2))
+            assert np.array_equal(ops.relu(x, inplace), O.relu(x)) and np.array_equal(ops.add(x, y, inplace), O.add(x, y))
+        n[what] += 1
+    print(f"ops_fuzz: {n}, seed {a.seed}: pools / relu / add bit-exact, batch-norm within 1 ulp, linear within tolerance")
+
+
+if __name__ == "__main__":
+    main()
