@@ -28,7 +28,7 @@ def main():
     lib, ctx = L.lib(), R.get_ctx()
     ncand = int(lib.rn_conv_tile_candidates())
     t0, cases, launches = time.time(), 0, 0
-    kinds = {"nchw": 0, "nhwc": 0, "fused": 0, "bf16": 0}
+    kinds = {"nchw": 0, "nhwc": 0, "fused": 0, "bf16": 0, "pair": 0, "exact": 0}
     while time.time() - t0 < a.seconds:
         k = int(g.choice([1, 1, 3, 3, 5, 7]))
         stride = int(g.choice([1, 1, 2, 3]))
@@ -44,8 +44,12 @@ def main():
         K = Cin * k * k
         want = O.conv2d(x, w, stride, pad)
         scale = float(np.abs(want).max()) + 1e-6
-        kind = str(g.choice(["nchw", "nhwc", "fused", "bf16"]))
+        kind = str(g.choice(["nchw", "nhwc", "fused", "bf16", "pair", "exact"]))
         if kind == "bf16" and (Cin % 64 or Cout % 8):  # the bf16 contraction: whole 128-byte channel segments
+            kind = "fused"
+        if kind == "exact" and not (Cin <= 4 and k <= 8 and Cout % 4 == 0):  # the small-Cin exact-K form
+            kind = "nhwc"
+        if kind == "pair" and not (Cin % 32 == 0 and Cout % 4 == 0 and stride == 1):
             kind = "fused"
         kinds[kind] += 1
         first = None
@@ -67,6 +71,24 @@ def main():
                     got = ops.conv2d_nhwc_fused(x, w, stride, pad, sc, sh, res, True)
                     ref = np.maximum(want * sc[None, :, None, None] + sh[None, :, None, None] + res, 0)
                     tol = 3e-7 * np.sqrt(K) * (float(np.abs(ref).max()) + scale) + 2e-6
+                elif kind == "exact":
+                    got = ops.conv2d_nhwc_exact(x, w, stride, pad)
+                    ref, tol = want, 3e-7 * np.sqrt(K) * scale + 1e-6
+                elif kind == "pair":
+                    # + a 1x1 convolution (stride s2) of a second tensor in the same K loop, scales folded
+                    if first is None:
+                        s2, Cin2 = int(g.choice([1, 2])), int(g.choice([32, 64, 96]))
+                        ho, wo = want.shape[2], want.shape[3]
+                        x2 = g.standard_normal((B, Cin2, (ho - 1) * s2 + 1, (wo - 1) * s2 + 1), dtype=np.float32)
+                        w2 = g.standard_normal((Cout, Cin2, 1, 1), dtype=np.float32) / np.sqrt(Cin2)
+                        sc1, sc2 = g.random(Cout, dtype=np.float32) + 0.5, g.random(Cout, dtype=np.float32) + 0.5
+                        shf = g.standard_normal(Cout, dtype=np.float32)
+                        ref = np.maximum(O.conv2d(x, w * sc1[:, None, None, None], stride, pad) +
+                                         O.conv2d(x2, w2 * sc2[:, None, None, None], s2, 0) + shf[None, :, None, None], 0)
+                        keep = (x2, w2, s2, sc1, sc2, shf, ref)
+                    x2, w2, s2, sc1, sc2, shf, ref = keep
+                    got = ops.conv2d_nhwc_pair(x, w, x2, w2, stride, pad, s2, sc1, sc2, shf, None, True)
+                    tol = 3e-7 * np.sqrt(K + x2.shape[1] + 4) * (float(np.abs(ref).max()) + scale) * 2 + 2e-6
                 else:
                     got = ops.conv2d_nhwc_bf16(x, w, stride, pad, None, None, None, False, out_f32=True)
                     ref = O.conv2d(ops.bf16_round(x), ops.bf16_round(w), stride, pad)
