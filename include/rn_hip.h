@@ -288,7 +288,9 @@ RN_API int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float
 /* per-op timing of the next forwards: 1 = bracket every op with events */
 /* Fused mode only: run conv3 + downsample of the first block of each stage as one contraction
  * (rn_conv2d_nhwc_pair_forward_dt); on by default, off = downsample first, then conv3 with it
- * as the residual.  Changing it invalidates the tuned tiles. */
+ * as the residual.  Changing it invalidates the tuned tiles.  NOT bit-neutral: the pair has one
+ * epilogue, so both batch-norm scales are folded into the weight rows (rounded once more) instead of
+ * multiplying the fp32 sums; both forms are within the fused mode's tolerance of the reference. */
 RN_API int rn_model_set_pair_fusion(rn_model *m, int on);
 /* fp32 models: stem through rn_conv2d_nhwc_exact_forward (K = 160; default) or through the
  * 4-channel / 8-slot form of rn_conv2d_nhwc_forward (K = 224).  Invalidates the tuned tiles. */
@@ -387,7 +389,10 @@ RN_API int rn_conv_chain_pair_forward_dt(rn_ctx *ctx, int dtype, const void *t2,
 RN_API int rn_model_set_chain(rn_model *m, int on);
 /* Fused mode: use it for conv1 + bn1 + relu + maxpool (default on; fp32 needs the exact-K stem
  * image, rn_model_set_stem_exact).  on == 2: through rn_stem_pool_nchw_forward_dt, the input
- * layout launch disappears as well.  Invalidates the tuned tiles. */
+ * layout launch disappears as well.  Invalidates the tuned tiles.  on = 1 and on = 2 give the same
+ * bits; on = 0 (stem and max-pool as separate launches) sums the 147 products of an output in another
+ * order (another K padding), so its results differ in the last bits -- which is why the model keeps
+ * ONE setting for every batch size. */
 RN_API int rn_model_set_stem_pool_fusion(rn_model *m, int on);
 
 /* ---- fused pair: out = epilogue(conv(inp, W1) + conv1x1(inp2, W2)) ------------------
