@@ -11,8 +11,52 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
+import resnet_c_amd as R
 from oracle import oracle as O
+from resnet_c_amd import _lib as L
 from resnet_c_amd import ops
+from resnet_c_amd.tensor import _DeviceBuffer
+
+
+def layout_case(g):
+    """rn_nchw_to_nhwc / rn_nhwc_to_nchw / rn_nchw_to_nhwc_pad_dt against numpy: pure data movement."""
+    lib, ctx = L.lib(), R.get_ctx()
+    B, C = int(g.integers(1, 6)), int(g.choice([1, 2, 3, 4, 5, 8, 31, 32, 64, 100]))
+    H, W = int(g.integers(1, 30)), int(g.integers(1, 30))
+    x = g.standard_normal((B, C, H, W), dtype=np.float32)
+    src = R.FloatTensor.from_numpy(x, R.Device.GPU)
+    which = str(g.choice(["plain", "back", "pad"]))
+    if which == "plain":
+        dst = R.FloatTensor((B, H, W, C), R.Device.GPU)
+        L.check(lib.rn_nchw_to_nhwc(ctx.handle, src.data(), dst.data(), B, C, H, W), "nchw_to_nhwc", ctx.handle)
+        ctx.sync()
+        assert np.array_equal(dst.numpy().reshape(B, H, W, C), x.transpose(0, 2, 3, 1)), f"nchw_to_nhwc {x.shape}"
+    elif which == "back":
+        nhwc = R.FloatTensor.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1)).reshape(B, H, W, C), R.Device.GPU)
+        dst = R.FloatTensor((B, C, H, W), R.Device.GPU)
+        L.check(lib.rn_nhwc_to_nchw(ctx.handle, nhwc.data(), dst.data(), B, C, H, W), "nhwc_to_nchw", ctx.handle)
+        ctx.sync()
+        assert np.array_equal(dst.numpy().reshape(B, C, H, W), x), f"nhwc_to_nchw {x.shape}"
+    else:
+        bf16 = bool(g.integers(0, 2))
+        Cpad = int(g.choice([C, C + 1, max(C, 4), ((C + 3) // 4) * 4]))
+        border = int(g.integers(0, 4))
+        Hp, Wp = H + 2 * border, W + 2 * border
+        want = np.zeros((B, Hp, Wp, Cpad), dtype=np.float32)
+        want[:, border:border + H, border:border + W, :C] = x.transpose(0, 2, 3, 1)
+        n = B * Hp * Wp * Cpad
+        dst = _DeviceBuffer(ctx, n * (2 if bf16 else 4))
+        L.check(lib.rn_nchw_to_nhwc_pad_dt(ctx.handle, L.RN_DTYPE_BF16 if bf16 else L.RN_DTYPE_F32, src.data(), dst.ptr,
+                                           B, C, H, W, Cpad, border), "pad_dt", ctx.handle)
+        ctx.sync()
+        if bf16:
+            h = np.empty(n, dtype=np.uint16)
+            L.check(lib.rn_memcpy_d2h(ctx.handle, h.ctypes.data, dst.ptr, h.nbytes), "d2h", ctx.handle)
+            assert np.array_equal(h, ops.to_bf16_bits(want.reshape(-1))), f"pad_dt bf16 {x.shape} Cpad={Cpad} border={border}"
+        else:
+            h = np.empty(n, dtype=np.float32)
+            L.check(lib.rn_memcpy_d2h(ctx.handle, h.ctypes.data, dst.ptr, h.nbytes), "d2h", ctx.handle)
+            assert np.array_equal(h, want.reshape(-1)), f"pad_dt f32 {x.shape} Cpad={Cpad} border={border}"
 
 
 def main():
@@ -21,7 +65,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     g = np.random.default_rng(a.seed)
-    t0, n = time.time(), {"maxpool": 0, "avgpool": 0, "batchnorm": 0, "linear": 0, "relu/add": 0}
+    t0, n = time.time(), {"maxpool": 0, "avgpool": 0, "batchnorm": 0, "linear": 0, "relu/add": 0, "layout": 0}
     while time.time() - t0 < a.seconds:
         what = str(g.choice(list(n)))
         layout = str(g.choice(["nchw", "nhwc"]))
@@ -58,13 +102,15 @@ def main():
             got = ops.linear(x, w, b)
             tol = 3e-7 * np.sqrt(I) * (float(np.abs(want).max()) + 1e-6) + 1e-6
             assert got.shape == want.shape and float(np.abs(got - want).max()) <= tol, f"linear {B}x{I}->{Oo}"
+        elif what == "layout":
+            layout_case(g)
         else:
             nel = int(g.choice([1, 3, 4, 5, 63, 64, 1000, 4097, 70001]))
             x, y = g.standard_normal(nel, dtype=np.float32), g.standard_normal(nel, dtype=np.float32)
             inplace = bool(g.integers(0, 2))
             assert np.array_equal(ops.relu(x, inplace), O.relu(x)) and np.array_equal(ops.add(x, y, inplace), O.add(x, y))
         n[what] += 1
-    print(f"ops_fuzz: {n}, seed {a.seed}: pools / relu / add bit-exact, batch-norm within 1 ulp, linear within tolerance")
+    print(f"ops_fuzz: {n}, seed {a.seed}: pools / relu / add / layout changes bit-exact, batch-norm within 1 ulp, linear within tolerance")
 
 
 if __name__ == "__main__":
