@@ -416,6 +416,12 @@ def test_bf16_pools():
     x = rnd((2, 64, 14, 14), 5)
     xb = ops.bf16_round(x)
     assert np.array_equal(ops.pool_nhwc_bf16(x, 3, 2, 1, True), O.maxpool2d(xb, 3, 2, 1))
+    for shape in ((2, 64, 112, 112), (1, 16, 33, 20)):   # eight or more output rows: the column walk
+        y = rnd(shape, 7 + shape[2])
+        y[0, 1, 4:9, :] = np.nan
+        y[0, 2, 0:6, 0:6] = -np.inf
+        got = ops.pool_nhwc_bf16(y, 3, 2, 1, True)
+        assert np.array_equal(got, O.maxpool2d(ops.bf16_round(y), 3, 2, 1)) and not np.isnan(got).any()
     x7 = rnd((2, 2048, 7, 7), 6)
     want = ops.bf16_round(O.avgpool2d(ops.bf16_round(x7), 7))
     assert np.array_equal(ops.pool_nhwc_bf16(x7, 7, 1, 0, False), want)

@@ -217,6 +217,20 @@ def test_maxpool_all_padding_window_and_nan():
     for layout in ("nchw", "nhwc"):
         got = ops.maxpool2d(y, 3, 2, 1, layout)
         assert np.array_equal(got, O.maxpool2d(y, 3, 2, 1)) and not np.isnan(got).any()
+    # the column walk of the NHWC form (eight or more output rows, channels a multiple of 4): odd and even
+    # heights, a lane's carried row maximum all NaN / all -inf, signed zeros, several row segments
+    for shape in ((2, 8, 33, 20), (1, 4, 64, 9), (3, 12, 16, 17)):
+        z = rnd(shape, 101 + sum(shape))
+        z[0, 0, 5, :] = np.nan
+        z[0, 1, 6:9, :] = np.nan
+        z[-1, 2, :, 3] = np.nan
+        z[0, 3, 0:8, 0:8] = -np.inf
+        z[-1, 0, 10:14, :] = 0.0
+        z[-1, 0, 11, ::2] = -0.0
+        got = ops.maxpool2d(z, 3, 2, 1, "nhwc")
+        want = O.maxpool2d(z, 3, 2, 1)
+        assert np.array_equal(got, want) and not np.isnan(got).any()
+        assert np.array_equal(np.signbit(got), np.signbit(want))
 
 
 @pytest.mark.parametrize("layout", ["nchw", "nhwc"])

@@ -77,6 +77,8 @@ def main():
             H, W = int(g.integers(max(1, k - 2 * p), 20)), int(g.integers(max(1, k - 2 * p), 20))
             if C >= 256:
                 H, W = min(H, 8), min(W, 8)
+            elif what == "maxpool" and g.random() < 0.3:  # the network's pool on taller images: the column walk
+                k, s, p, H = 3, 2, 1, int(g.integers(15, 60))
             if what == "avgpool" and g.random() < 0.4:  # the global pool of the network's tail
                 H = W = k = 7
                 s, p = int(g.choice([1, 7])), 0
