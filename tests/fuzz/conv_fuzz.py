@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
 """Randomised parity run of the convolution entry points against the CPU oracle (test
-infrastructure, like tests/: the product never imports oracle/).  Shapes, strides, paddings, layouts,
+infrastructure under tests/: nothing outside tests/, smoke() and bench.py's CPU baseline touches oracle/).  Shapes, strides, paddings, layouts,
 storage types, epilogues and tile candidates are drawn at random; every tile candidate of a case
 must give the bits of the first one.
 
-    python tools/conv_fuzz.py [--seconds 60] [--seed 0]"""
+    python tests/fuzz/conv_fuzz.py [--seconds 60] [--seed 0]"""
 import argparse
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 import resnet_c_amd as R

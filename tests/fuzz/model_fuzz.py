@@ -6,13 +6,13 @@ scales into the weights / use another K padding and so round differently).  None
 equal the ones a plain forward of the whole pool gave at the start (batch invariance), whatever ran
 before -- arenas resized, scratch regrown, tiles tuned at another batch size.
 
-    python tools/model_fuzz.py [--seconds 60] [--seed 0] [--dtype f32|bf16] [--arch resnet50]"""
+    python tests/fuzz/model_fuzz.py [--seconds 60] [--seed 0] [--dtype f32|bf16] [--arch resnet50]"""
 import argparse
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 import resnet_c_amd as R

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Randomised parity run of the element-wise, pooling, batch-norm and linear entry points against the
-CPU oracle, both layouts (test infrastructure, like tests/).
+CPU oracle, both layouts (test infrastructure under tests/).
 
-    python tools/ops_fuzz.py [--seconds 60] [--seed 0]"""
+    python tests/fuzz/ops_fuzz.py [--seconds 60] [--seed 0]"""
 import argparse
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 
 import resnet_c_amd as R

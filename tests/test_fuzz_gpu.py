@@ -1,8 +1,8 @@
-"""Short runs of the randomised parity tools (tools/conv_fuzz.py, ops_fuzz.py, model_fuzz.py) with
+"""Short runs of the randomised parity programs (tests/fuzz/conv_fuzz.py, ops_fuzz.py, model_fuzz.py) with
 fixed seeds: every convolution entry point over random shapes / layouts / storage types / tile
 candidates against the CPU oracle, the element-wise / pooling / batch-norm / linear entry points, and
 the model driver's state machine (no switch that only reschedules the arithmetic may change a bit).
-The long runs (minutes, other seeds) are a tool matter; these keep the paths exercised in every run
+The long runs (minutes, other seeds) are started by hand; these keep the paths exercised in every run
 of the suite.  Each tool exits non-zero with the failing case in its assertion message."""
 import os
 import subprocess
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run_tool(name, *args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", name), *args], cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", name), *args], cwd=ROOT,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, f"{name} {' '.join(args)}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
     return r.stdout

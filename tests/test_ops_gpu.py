@@ -616,7 +616,7 @@ def test_one_thread_two_contexts_interleaved():
                                   (2, 64, 128, 8, 8, 1, 2, 0),       # stride 2 (the projection shortcuts)
                                   (3, 256, 72, 9, 7, 1, 2, 0),       # stride 2 on odd sizes
                                   (2, 48, 64, 8, 8, 1, 1, 0),        # Cin not a multiple of 32: the direct kernel, another order
-                                  (2, 32, 256, 1, 3, 1, 3, 0),       # ONE output pixel per image (found by tools/conv_fuzz.py:
+                                  (2, 32, 256, 1, 3, 1, 3, 0),       # ONE output pixel per image (found by tests/fuzz/conv_fuzz.py:
                                   (5, 64, 40, 1, 1, 1, 1, 0),        #  the q / HW multiply-high has no form for HW = 1)
                                   (3, 96, 64, 5, 1, 1, 1, 0)])       # one-pixel-wide planes
 def test_nchw_route_writes_the_nhwc_routes_bits(case):
