@@ -99,6 +99,58 @@ def max_over_ranks(value: float, world: int, device=None) -> float:
     return float(t.item())
 
 
+def device_locality(device_index: int, bind: bool):
+    """Where this rank's device sits in the host (rn_device_locality: PCI address, NUMA node, local CPUs) and,
+    with `bind`, this process moved onto those cores (the ones it may use; RN_SHARD_AFFINITY=0 turns it off):
+    on a two-socket 8-GPU node half of the ranks would otherwise launch from the far socket."""
+    import ctypes
+
+    import resnet_c_amd as R
+
+    pci, cpus, node = ctypes.create_string_buffer(32), ctypes.create_string_buffer(256), ctypes.c_int(-1)
+    if R._lib.lib().rn_device_locality(device_index, pci, 32, ctypes.byref(node), cpus, 256) != 0:
+        return {}
+    out = {"pci": pci.value.decode(), "numa_node": node.value, "local_cpus": cpus.value.decode(), "bound": False}
+    if bind and out["local_cpus"] and os.environ.get("RN_SHARD_AFFINITY", "1")[:1] != "0":
+        local = set()
+        for part in out["local_cpus"].split(","):
+            a, _, b = part.partition("-")
+            local |= set(range(int(a), int(b or a) + 1))
+        both = local & os.sched_getaffinity(0)
+        if both:
+            try:
+                os.sched_setaffinity(0, both)
+                out["bound"] = True
+            except OSError:
+                pass
+    out["cpus_allowed"] = len(os.sched_getaffinity(0))
+    return out
+
+
+def gather_ranks(me: dict, world: int):
+    """Every rank's own record (rank, device, its own ms_per_step ...) on every rank, in rank order."""
+    if world == 1:
+        return [me]
+    import torch.distributed as dist
+
+    ranks = [None] * dist.get_world_size()
+    dist.all_gather_object(ranks, me)
+    return ranks
+
+
+def world_block(ranks, size, backend):
+    """The bench line's `world` object: what torch.distributed saw, every rank's device and its OWN time
+    for the K steps (before it waited for the others), so that a straggler -- a slow device, a host thread
+    on the wrong socket -- is visible next to the max-over-ranks time the value is computed from."""
+    out = {"size": size, "backend": backend, "ranks": ranks}
+    times = [r["ms_per_step"] for r in ranks if "ms_per_step" in r]
+    if times:
+        out["slowest_rank_ms_per_step"] = max(times)
+        out["fastest_rank_ms_per_step"] = min(times)
+        out["slowest_rank"] = max(ranks, key=lambda r: r.get("ms_per_step", 0.0))["rank"]
+    return out
+
+
 def cpu_baseline(arch: str, state, seconds_budget: float = 30.0, engine=None, batch: int = 256):
     """Reference-equivalent PyTorch forward on the host CPU, bounded sample.  `engine`: a callable
     (NCHW fp32 array -> logits) of the GPU path; the port's logits on the sample's first images
@@ -267,23 +319,22 @@ def main():
     # who takes part: the launcher's world size as torch.distributed sees it, and every rank's device
     me = {"rank": rank, "local_rank": local_rank, "device_index": device_index,
           "device": torch.cuda.get_device_name(device_index), "pid": os.getpid()}
-    ranks = [me]
     dist_world, dist_backend = 1, None
     if world > 1:
         import torch.distributed as dist
 
         dist_world, dist_backend = dist.get_world_size(), dist.get_backend()
-        ranks = [None] * dist_world
-        dist.all_gather_object(ranks, me)
+    me.update(device_locality(device_index, bind=world > 1))
     print(f"bench: rank {rank}/{dist_world} ({dist_backend or 'single process'}) on cuda:{device_index} "
           f"{me['device']}", file=sys.stderr, flush=True)
 
     B = args.batch
     state = R.weights.generate_state(args.arch, seed=0)
     model = R.NativeModel(args.arch, state=state, ctx=ctx, dtype=args.dtype)
-    if args.streams:
-        model.set_streams(args.streams)
-    args.streams = model.parts(B)  # what a forward of B images runs as (library default: by dtype and B)
+    cfg_streams = args.streams     # what was asked for: 0 = the library default
+    if cfg_streams:
+        model.set_streams(cfg_streams)
+    parts = model.parts(B)         # what a forward of B images actually runs as (by dtype, B and the setting)
     model.set_front_parts(args.front_parts)
     lo, hi = shard_bounds(world * B, rank, world)
     # this rank's shard of the global batch: image i depends on (seed, i) only
@@ -310,16 +361,22 @@ def main():
         model.forward_ptr(x_dev.data(), B, logits.data(), fused)
     ctx.sync()
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0     # this rank's own K steps, before it waits for the others
     barrier(world)
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, world, device=torch.device("cuda", device_index))
+    # every rank's own time next to the max: a straggler (a slow device, a host thread on the wrong
+    # socket) shows in the line instead of only stretching the job's time
+    me["ms_per_step"] = round(own / args.steps * 1e3, 4)
+    me["images_per_s"] = round(B * args.steps / own, 1)
+    ranks = gather_ranks(me, world)
 
     out = logits.numpy()
     assert np.isfinite(out).all(), "non-finite logits"
 
     # the same steps with the whole batch on ONE stream (what the roofline block below describes)
     ms_one_stream = elapsed / args.steps * 1e3
-    if args.streams > 1:
+    if parts > 1:
         model.set_streams(1)
         for _ in range(2):
             model.forward_ptr(x_dev.data(), B, logits.data(), fused)
@@ -329,7 +386,8 @@ def main():
             model.forward_ptr(x_dev.data(), B, logits.data(), fused)
         ctx.sync()
         ms_one_stream = (time.perf_counter() - t1) / args.steps * 1e3
-        model.set_streams(args.streams)
+        model.set_streams(cfg_streams)  # 0: back to the library default, exactly as the timed region ran
+        assert model.parts(B) == parts
         assert np.array_equal(logits.numpy(), out), "one stream and several must give the same bits"
 
     # per-kernel durations: HIP events on the library's stream around every op
@@ -414,7 +472,8 @@ def main():
                                   else "(BASELINE.json configs[4])"),
                    "global_batch": world * B, "batch_per_gpu": B,
                    "mode": "fused conv+bn+relu(+add) epilogues" if fused else "one kernel per reference op",
-                   "streams_per_gpu": args.streams, "front_parts": args.front_parts,
+                   "streams_per_gpu": parts, "streams_configured": cfg_streams or "library default",
+                   "front_parts": args.front_parts,
                    "parallelism": f"batch split over {world} GPU(s), weights replicated, no collective"},
         "roofline": {"bound": bound,
                      "achieved": round(achieved, 2) if bound == "mfma" else round(g_gbps, 1),
@@ -436,7 +495,7 @@ def main():
                                     "timed region, whole batch on ONE stream (with streams_per_gpu > 1 the timed "
                                     "region overlaps the kernels of the batch parts, so their sum exceeds "
                                     "ms_per_step)" % args.profile_forwards},
-        "world": {"size": dist_world, "backend": dist_backend, "ranks": ranks},
+        "world": world_block(ranks, dist_world, dist_backend),
         "whole_step_mfma_frac": round(value / world * GFLOP_PER_IMAGE[args.arch] / 1e3 / peak, 4),
         "hbm_kernels": hbm,
     }

@@ -131,6 +131,11 @@ RN_API int rn_sync(rn_ctx *ctx);
 RN_API const char *rn_last_error(const rn_ctx *ctx);
 RN_API const char *rn_status_string(int status);
 RN_API int rn_device_count(int *count);
+/* Where a device sits in the host: PCI address ("0000:c1:00.0"), the NUMA node of its slot and the
+ * CPUs local to it as Linux lists them ("0-47,96-143"); -1 / "" where sysfs does not say.  The
+ * host threads of rn_shard_* run on those cores. */
+RN_API int rn_device_locality(int device, char *pci_bus_id, uint64_t pci_cap, int *numa_node,
+                              char *cpulist, uint64_t cpulist_cap);
 RN_API const char *rn_version(void);
 
 /* ---- buffers ------------------------------------------------------------ */
@@ -285,6 +290,14 @@ RN_API int rn_model_forward(rn_model *m, const float *input_nchw, uint64_t B, fl
  * device (events on the context's stream, on the buffers that forward used) and remember the fastest per layer for
  * that batch size.  Results do not change (candidates are bit-identical), only speed. */
 RN_API int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logits, int mode);
+/* The table that rn_model_tune filled, as 64-bit words (header: architecture, element type, fusion
+ * settings, batch, mode, candidate count of the build; then the (tile, launch batch) slots of every
+ * layer), and its way into another model of the same architecture / element type / settings on an
+ * identical device: the shards of a node take over ONE shard's measurement (rn_shard_tune), a later
+ * process a stored one.  export with words == NULL returns the size in *n_words; import refuses a
+ * table measured for anything else (RN_ERR_INVALID, nothing changed).  Tiles change speed only. */
+RN_API int rn_model_export_tuning(const rn_model *m, uint64_t *words, uint64_t cap, uint64_t *n_words);
+RN_API int rn_model_import_tuning(rn_model *m, const uint64_t *words, uint64_t n_words);
 /* per-op timing of the next forwards: 1 = bracket every op with events */
 /* Fused mode only: run conv3 + downsample of the first block of each stage as one contraction
  * (rn_conv2d_nhwc_pair_forward_dt); on by default, off = downsample first, then conv3 with it
@@ -303,7 +316,8 @@ RN_API int rn_model_set_stem_exact(rn_model *m, int on);
  * only into parts of at least 128 images (parts of 96 measured 3 % slower than one stream, parts
  * of 64 equal).  Profiled and tuning forwards always use one stream.  Tuned tiles
  * are kept per launch batch size (rn_model_tune times the parts' size and the whole batch), so
- * switching between the tuned part count and one stream keeps them. */
+ * switching between the tuned part count and one stream keeps them.  streams = 0 returns to the
+ * library default (as if this function had never been called). */
 RN_API int rn_model_set_streams(rn_model *m, int streams);
 RN_API int rn_model_get_streams(const rn_model *m);
 /* the number of parts (streams) a forward of B images actually runs as under the rule above */
@@ -383,9 +397,7 @@ RN_API int rn_conv_chain_pair_forward_dt(rn_ctx *ctx, int dtype, const void *t2,
                                          const float *shift1, uint64_t rows, uint64_t mid_channels,
                                          uint64_t in2_channels, uint64_t channels, uint64_t next_mid);
 /* Fused mode: conv3 of a block and conv1 of the block after it as one launch where a chain kernel
- * exists (rn_conv_chain_forward_dt; default on = 1).  2: also the 256-channel blocks of stage 3 with
- * bf16 storage, whose chain kernel streams both weight panels through LDS and is SLOWER than its two
- * launches (kept for measurement).  The same bits whatever the setting. */
+ * exists (rn_conv_chain_forward_dt; default on).  The same bits whatever the setting. */
 RN_API int rn_model_set_chain(rn_model *m, int on);
 /* Fused mode: use it for conv1 + bn1 + relu + maxpool (default on; fp32 needs the exact-K stem
  * image, rn_model_set_stem_exact).  on == 2: through rn_stem_pool_nchw_forward_dt, the input
@@ -431,7 +443,11 @@ RN_API int rn_conv2d_nhwc_pair_forward_dt(rn_ctx *ctx, int dtype, int out_dtype,
  * (call rn_model_tune before).  Needs profiling and sync_each_op off (RN_ERR_INVALID otherwise).
  * The buffers must stay valid while the graph lives; while any graph of a context lives, a
  * call that would have to grow the context's scratch or the model's activation arenas (a
- * larger batch than any before) returns RN_ERR_INVALID instead of moving them. */
+ * larger batch than any before) returns RN_ERR_INVALID instead of moving them.
+ * Teardown order: rn_graph_destroy, then rn_model_destroy, then rn_ctx_destroy.  A graph points into
+ * its model's arenas and into the scratch of the contexts the model owns for its extra streams:
+ * rn_model_destroy returns RN_ERR_INVALID (and frees nothing) while a graph captured from the model
+ * lives. */
 typedef struct rn_graph rn_graph;
 RN_API int rn_model_capture(rn_model *m, const float *input_nchw, uint64_t B, float *logits,
                             int mode, rn_graph **out);
@@ -484,8 +500,24 @@ RN_API int rn_shard_set_dtype(rn_shard *g, int dtype);
 RN_API int rn_shard_finalize(rn_shard *g);
 RN_API int rn_shard_forward(rn_shard *g, const float *host_input_nchw, uint64_t B,
                             float *host_logits, uint64_t *host_top1, int mode);
-/* rn_model_tune on every shard, at the batch size each shard sees for a batch of B */
+/* Tuned tiles for the launches the group will issue for batches of B: with a stream open
+ * (rn_shard_stream_open) those of a whole shard per device, otherwise those of rn_shard_forward's
+ * chunks (at most 128 images).  ONE shard measures (rn_model_tune on shard 0, the other devices
+ * idle), the shards with the same share take its table over (rn_model_import_tuning: identical
+ * devices, and every shard then runs the same tiles); a shard with another share (uneven split)
+ * measures for itself.  Refused while submitted batches are in flight. */
 RN_API int rn_shard_tune(rn_shard *g, const float *host_input_nchw, uint64_t B, int mode);
+/* Where shard `rank` runs: its device, the NUMA node of that device and the CPUs its host thread was
+ * bound to ("" = not bound).  A shard's thread is bound to the cores local to its device
+ * (rn_device_locality, intersected with the cores the process may use) when it starts: it copies every
+ * batch from the caller's pageable memory into pinned staging, and on a two-socket node the remote
+ * socket's memory path halves that copy.  Best effort; RN_SHARD_AFFINITY=0 in the environment turns it off. */
+RN_API int rn_shard_placement(const rn_shard *g, int rank, int *device, int *numa_node, char *cpulist,
+                              uint64_t cpulist_cap);
+/* Shard `rank`'s model, for settings and queries (rn_model_set_streams, rn_model_export_tuning ...)
+ * between calls on the group, when its host thread is parked.  Owned by the group; running a forward
+ * on it from the caller's thread is not supported (its context belongs to the shard's thread). */
+RN_API rn_model *rn_shard_model(rn_shard *g, int rank);
 /* Upload, forward and download overlap on every device (main.cu:236-240 and tensor.cuh:184-199
  * do them strictly in sequence, from pageable memory): each device owns an rn_pipeline -- pinned
  * staging, a copy stream, two slots.  rn_shard_forward sends a shard through it in chunks of at

@@ -12,7 +12,11 @@
  *   - padded taps are skipped, not multiplied by zero,
  *   - `sum += a * b` is restated as fmaf(a, b, sum) because nvcc contracts
  *     that statement to an FMA by default,
- *   - batch-norm evaluated in double and rounded once (cuda/ops.cu:149-150),
+ *   - batch-norm as cuda/ops.cu:149-150 types it: `inp - mean[c]` is float - float, an
+ *     fp32 subtraction; `var[c] + 1e-5` promotes to double (the literal is one), so the
+ *     square root, the divide, `* weight[c]` and `+ bias[c]` are double and the result is
+ *     rounded to fp32 once at the store.  `q * weight + bias` is one double fma here
+ *     because nvcc contracts it (-fmad=true is its default; same rule as the conv sums),
  *   - average pool divides twice by (float)kernel_size (cuda/ops.cu:107).
  *
  * The loops are arranged so that the innermost loop runs over output columns
@@ -248,7 +252,9 @@ RN_ORACLE_API void rn_oracle_relu(const float *inp, float *out, uint64_t N)
     }
 }
 
-/* cuda/ops.cu:139-151; the 1e-5 literal is a double, so the whole expression is. */
+/* cuda/ops.cu:139-151.  The subtraction has two float operands: it is an fp32 subtraction.
+ * The 1e-5 literal is a double, so from `var[c] + 1e-5` on (sqrt, divide, multiply, add) the
+ * expression is double; the multiply-add is contracted to an fma as nvcc does by default. */
 RN_ORACLE_API void rn_oracle_batchnorm2d(const float *inp, float *out, const float *weight,
                                          const float *bias, const float *mean, const float *var,
                                          uint64_t B, uint64_t C, uint64_t N)
@@ -258,11 +264,13 @@ RN_ORACLE_API void rn_oracle_batchnorm2d(const float *inp, float *out, const flo
     for (int64_t p = 0; p < planes; ++p) {
         const int64_t c = p % (int64_t)C;
         const double denom = sqrt((double)var[c] + 1e-5);
-        const double m = (double)mean[c], g = (double)weight[c], beta = (double)bias[c];
+        const float m = mean[c];
+        const double g = (double)weight[c], beta = (double)bias[c];
         const float *src = inp + (size_t)p * N;
         float *dst = out + (size_t)p * N;
         for (uint64_t n = 0; n < N; ++n) {
-            dst[n] = (float)(((double)src[n] - m) / denom * g + beta);
+            const float a = src[n] - m; /* fp32, ops.cu:150 */
+            dst[n] = (float)fma((double)a / denom, g, beta);
         }
     }
 }

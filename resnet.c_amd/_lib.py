@@ -54,6 +54,7 @@ SIGNATURES = {
     "rn_last_error": (c_char_p, [c_void_p]),
     "rn_status_string": (c_char_p, [c_int]),
     "rn_device_count": (c_int, [POINTER(c_int)]),
+    "rn_device_locality": (c_int, [c_int, c_char_p, u64, POINTER(c_int), c_char_p, u64]),
     "rn_version": (c_char_p, []),
     "rn_malloc": (c_int, [c_void_p, POINTER(c_void_p), u64]),
     "rn_free": (c_int, [c_void_p, c_void_p]),
@@ -124,6 +125,8 @@ SIGNATURES = {
     "rn_model_tensor_key": (c_char_p, [c_void_p, u64, POINTER(u64)]),
     "rn_model_forward": (c_int, [c_void_p, fptr, u64, fptr, c_int]),
     "rn_model_tune": (c_int, [c_void_p, fptr, u64, fptr, c_int]),
+    "rn_model_export_tuning": (c_int, [c_void_p, POINTER(u64), u64, POINTER(u64)]),
+    "rn_model_import_tuning": (c_int, [c_void_p, POINTER(u64), u64]),
     "rn_model_set_profiling": (c_int, [c_void_p, c_int]),
     "rn_model_profile_count": (u64, [c_void_p]),
     "rn_model_profile_get": (c_int, [c_void_p, u64, POINTER(c_char_p), POINTER(c_char_p),
@@ -152,6 +155,8 @@ SIGNATURES = {
     "rn_shard_finalize": (c_int, [c_void_p]),
     "rn_shard_forward": (c_int, [c_void_p, c_void_p, u64, c_void_p, c_void_p, c_int]),
     "rn_shard_tune": (c_int, [c_void_p, c_void_p, u64, c_int]),
+    "rn_shard_model": (c_void_p, [c_void_p, c_int]),
+    "rn_shard_placement": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), c_char_p, u64]),
     "rn_shard_stream_open": (c_int, [c_void_p, u64, c_int]),
     "rn_shard_stream_buffer": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(u64), POINTER(u64)]),
     "rn_shard_submit": (c_int, [c_void_p, c_void_p]),

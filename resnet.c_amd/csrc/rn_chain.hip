@@ -653,9 +653,7 @@ int chain_launch(rn_ctx *ctx, const char *what, int dtype, const void *t2, const
     RN_REQUIRE(ctx, y != t1 && y != t2 && y != x && t1 != t2 && t1 != x, "y and t1 must not alias each other or an input");
     const bool s1 = mid_channels == 64 && channels == 256 && (next_mid == 64 || next_mid == 128);
     const bool s2 = mid_channels == 128 && channels == 512 && next_mid == 128 && !dual && dtype == RN_DTYPE_BF16;
-    const bool s3 = mid_channels == 256 && channels == 1024 && next_mid == 256 && !dual && dtype == RN_DTYPE_BF16;
-    RN_REQUIRE(ctx, s1 || s2 || s3,
-               "shapes: 64 -> 256 -> 64 | 128 channels, or (bf16) 128 -> 512 -> 128, 256 -> 1024 -> 256");
+    RN_REQUIRE(ctx, s1 || s2, "shapes: 64 -> 256 -> 64 | 128 channels, or (bf16) 128 -> 512 -> 128");
     RN_REQUIRE(ctx, !(dual && dtype == RN_DTYPE_F32 && next_mid != 64), "fp32 pair chain: next_mid 64");
     const uint64_t es = dtype == RN_DTYPE_BF16 ? 2 : 4;
     RN_REQUIRE(ctx, rows * channels * es < (1ull << 31), "tensor too large");
@@ -674,10 +672,6 @@ int chain_launch(rn_ctx *ctx, const char *what, int dtype, const void *t2, const
             chain32_kernel<64><<<grid, block, 0, ctx->stream>>>(q);
         else
             chain32_kernel<128><<<grid, block, 0, ctx->stream>>>(q);
-        return rn_after_launch(ctx, what);
-    }
-    if (s3) {  // the panels stream through LDS (rn_chain_wide.hip)
-        RN_TRY(rn_chain_wide_launch(ctx, t2, x, y, w3, scale3, shift3, t1, w1, scale1, shift1, rows));
         return rn_after_launch(ctx, what);
     }
     ChainParams p;

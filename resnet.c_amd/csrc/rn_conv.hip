@@ -987,15 +987,6 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
         }
     }
 
-    // fp32 3x3 / 64 -> 64 channels (stage 1's conv2): the fp32 strip kernel (rn_conv_strip32.hip) as the
-    // tuner's "strip" candidate; the same bits.  Not the untuned choice: measured, it runs at the tile
-    // kernels' pace (491 against 500 us at B = 256) -- both sit at the same 83 % matrix-pipe duty.
-    if (dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32 && ctx->split_k <= 1 && second == nullptr && !exact &&
-        ctx->conv_tile == 9 + rn_conv_wide_count() && rn_conv_strip32_eligible(p)) {
-        rn_conv_strip32_launch(ctx, p);
-        return rn_after_launch(ctx, what);
-    }
-
     // tile choice: the contraction is matrix-core bound, so a launch takes about
     // ceil(tiles / 256 CUs) rounds of one tile's MFMA time; pick the candidate with the
     // least (rounds * tile area / relative tile efficiency), i.e. the least padded,

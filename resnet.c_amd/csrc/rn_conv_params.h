@@ -115,11 +115,6 @@ void rn_conv_wide_launch(rn_ctx *ctx, rn_gemm::GemmParams &p, int which, bool du
 bool rn_conv_strip_eligible(const rn_gemm::GemmParams &p);
 void rn_conv_strip_launch(rn_ctx *ctx, const rn_gemm::GemmParams &p);
 
-// fp32 3x3 / stride 1 / 64 -> 64 channels with the weights in registers and the input in a rolling LDS
-// ring (rn_conv_strip32.hip): the fp32 model's stage-1 conv2; same bits as the tile kernels.
-bool rn_conv_strip32_eligible(const rn_gemm::GemmParams &p);
-void rn_conv_strip32_launch(rn_ctx *ctx, const rn_gemm::GemmParams &p);
-
 // fp32 1x1 / padding 0 convolution on NCHW tensors with the OIHW weight as it is (rn_conv_nchw.hip):
 // the literal drop-in route's rn_conv2d_forward without the input transpose.  Same bits as the
 // NHWC contraction.
@@ -127,11 +122,5 @@ bool rn_conv1x1_nchw_eligible(uint64_t kernel_size, uint64_t stride, uint64_t pa
                               uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W);
 int rn_conv1x1_nchw_launch(rn_ctx *ctx, const float *inp, float *out, const float *weight, uint64_t stride,
                            uint64_t B, uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W);
-
-// rn_chain_wide.hip: conv3 (256 -> 1024, residual) + next conv1 (1024 -> 256) of the stage-3 blocks, bf16;
-// the caller has checked alignment, aliasing and the shapes
-int rn_chain_wide_launch(rn_ctx *ctx, const void *t2, const void *x, void *y, const void *w3, const float *sc3,
-                         const float *sh3, void *t1, const void *w1, const float *sc1, const float *sh1,
-                         uint64_t rows);
 
 #endif

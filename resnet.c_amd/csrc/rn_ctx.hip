@@ -2,6 +2,7 @@
 // (reference cuda/tensor.cuh:59-245, cuda/helpers.cuh:6-35), as status-returning C.
 #include <errno.h>
 #include <stdarg.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -154,6 +155,39 @@ int rn_device_count(int *count)
     return RN_OK;
 }
 
+// Where a device sits in the host: its PCI address, the NUMA node of that slot and the CPUs local to
+// it, as Linux reports them (/sys/bus/pci/devices/<address>/numa_node, local_cpulist).  A host thread
+// that feeds a device (pageable -> pinned copies, launches) should run on those cores: on a two-socket
+// 8-GPU node half of the devices hang off the other socket.  Missing sysfs entries are not an error:
+// numa_node = -1, cpulist = "".
+int rn_device_locality(int device, char *pci_bus_id, uint64_t pci_cap, int *numa_node, char *cpulist,
+                       uint64_t cpulist_cap)
+{
+    char addr[32] = {0}, path[128];
+    if (numa_node) *numa_node = -1;
+    if (cpulist && cpulist_cap) cpulist[0] = 0;
+    if (pci_bus_id && pci_cap) pci_bus_id[0] = 0;
+    if (hipDeviceGetPCIBusId(addr, (int)sizeof(addr) - 1, device) != hipSuccess) return RN_ERR_HIP;
+    for (char *c = addr; *c; ++c)
+        if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');  // sysfs spells the address in lower case
+    if (pci_bus_id && pci_cap) snprintf(pci_bus_id, (size_t)pci_cap, "%s", addr);
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", addr);
+    if (FILE *f = fopen(path, "r")) {
+        int node = -1;
+        if (fscanf(f, "%d", &node) == 1 && numa_node) *numa_node = node;
+        fclose(f);
+    }
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", addr);
+    if (FILE *f = fopen(path, "r")) {
+        if (cpulist && cpulist_cap && fgets(cpulist, (int)cpulist_cap, f)) {
+            for (char *c = cpulist; *c; ++c)
+                if (*c == '\n') *c = 0;
+        }
+        fclose(f);
+    }
+    return RN_OK;
+}
+
 int rn_ctx_create(rn_ctx **out, int device, void *hip_stream)
 {
     if (!out) return RN_ERR_INVALID;
@@ -227,7 +261,7 @@ int rn_ctx_set_conv_tile(rn_ctx *ctx, int candidate)
     return RN_OK;
 }
 
-int rn_conv_tile_candidates(void) { return 8 + rn_conv_wide_count() + 1; }  // + the strip kernel
+int rn_conv_tile_candidates(void) { return 8 + rn_conv_wide_count() + 1; }  // + the bf16 strip kernels
 
 // library-internal (rn_model.c is plain C and sees the context only through functions)
 int rn_ctx_graphs_live(const rn_ctx *ctx) { return ctx ? ctx->graphs_live : 0; }

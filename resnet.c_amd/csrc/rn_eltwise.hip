@@ -5,15 +5,18 @@
 // roofline is HBM: relu 8 B/element, add 12 B/element, batch-norm 8 B/element
 // plus 16 B per channel of parameters.
 //
-// Batch-norm keeps the reference's arithmetic (cuda/ops.cu:149-150): because
-// `1e-5` is a double literal the whole expression is evaluated in double and
-// rounded to fp32 once at the store.  d = sqrt(var[c] + 1e-5) depends on the
-// channel only, so a tiny prologue kernel evaluates d and 1/d once per channel
-// (same double values the reference recomputes per element) into context
-// scratch.  The per-element quotient (x - mean) / d is then formed as
-// q0 = a * (1/d); r = fma(-q0, d, a); q = fma(r, 1/d, q0), which is the correctly
-// rounded double quotient (Markstein) at 3 FMAs -- a full IEEE v_div sequence per
-// element made this kernel compute-bound at 2.1 TB/s instead of HBM-bound.
+// Batch-norm keeps the reference's arithmetic (cuda/ops.cu:149-150) type by type:
+// `inp - mean[c]` has two float operands and is an fp32 subtraction (v_sub_f32);
+// `1e-5` is a double literal, so `var[c] + 1e-5`, the square root, the divide, the
+// multiply by weight[c] and the add of bias[c] are double, rounded to fp32 once at the
+// store.  `q * weight + bias` is ONE double fma: nvcc contracts it by default, and it is
+// written as fma() here so that it does not hang on a compiler flag.
+// d = sqrt(var[c] + 1e-5) depends on the channel only; d and 1/d are derived once per
+// channel (same double values the reference recomputes per element).  The per-element
+// quotient a / d is then formed as q0 = a * (1/d); r = fma(-q0, d, a);
+// q = fma(r, 1/d, q0), which is the correctly rounded double quotient (Markstein) at
+// 3 FMAs -- a full IEEE v_div sequence per element made this kernel compute-bound at
+// 2.1 TB/s instead of HBM-bound.
 #include "rn_internal.h"
 
 namespace {
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void add_scalar_kernel(const float *a, cons
         out[i] = a[i] + b[i];
 }
 
-constexpr int kBnStride = 8;  // doubles per channel: {mean, d, 1/d, weight, bias, pad x3}
+constexpr int kBnStride = 8;  // doubles per channel: {mean (an fp32 value), d, 1/d, weight, bias, pad x3}
 
 __global__ void bn_prep_kernel(const float *weight, const float *bias, const float *mean,
                                const float *var, double *params, uint64_t C)
@@ -93,21 +96,22 @@ __global__ void bn_prep_kernel(const float *weight, const float *bias, const flo
 
 __device__ __forceinline__ float bn_apply(float x, const double *p)
 {
-    const double a = (double)x - p[0];
+    const double a = (double)(x - (float)p[0]);  // fp32 subtraction, ops.cu:150
     const double q0 = a * p[2];
     const double r = fma(-q0, p[1], a);
-    const double q = fma(r, p[2], q0);  // == a / d, correctly rounded
-    return (float)(q * p[3] + p[4]);
+    const double q = (r == r) ? fma(r, p[2], q0) : q0;  // == a / d, correctly rounded; a = +-inf or d = 0: r is NaN, q0 already is the quotient
+    return (float)fma(q, p[3], p[4]);
 }
 
 struct BnParams {
-    double m, d, rinv, g, beta;
+    float m;
+    double d, rinv, g, beta;
 };
 
 __device__ __forceinline__ BnParams bn_load(const double *p)
 {
     BnParams q;
-    q.m = p[0], q.d = p[1], q.rinv = p[2], q.g = p[3], q.beta = p[4];
+    q.m = (float)p[0], q.d = p[1], q.rinv = p[2], q.g = p[3], q.beta = p[4];
     return q;
 }
 
@@ -118,7 +122,7 @@ __device__ __forceinline__ BnParams bn_derive(const float *weight, const float *
     BnParams q;
     q.d = sqrt((double)var[c] + 1e-5);
     q.rinv = 1.0 / q.d;
-    q.m = (double)mean[c];
+    q.m = mean[c];
     q.g = (double)weight[c];
     q.beta = (double)bias[c];
     return q;
@@ -126,11 +130,11 @@ __device__ __forceinline__ BnParams bn_derive(const float *weight, const float *
 
 __device__ __forceinline__ float bn_apply_reg(float x, const BnParams &p)
 {
-    const double a = (double)x - p.m;
+    const double a = (double)(x - p.m);  // fp32 subtraction, ops.cu:150
     const double q0 = a * p.rinv;
     const double r = fma(-q0, p.d, a);
-    const double q = fma(r, p.rinv, q0);
-    return (float)(q * p.g + p.beta);
+    const double q = (r == r) ? fma(r, p.rinv, q0) : q0;  // infinite a or d = 0: r is NaN and q0 already is a / d
+    return (float)fma(q, p.g, p.beta);
 }
 
 // NCHW, N % 4 == 0: one wave walks one (b, c) plane at a time, so the channel's five

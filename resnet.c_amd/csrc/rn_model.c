@@ -99,6 +99,7 @@ struct rn_model {
     int pair_fusion;  /* fused mode: conv3 + downsample as one contraction (default on) */
     int stem_exact;   /* fp32: stem in the exact-K form, K = 160 instead of 224 (default on) */
     float *stem_packed_exact;
+    int graphs_live;         /* graphs captured from this model that still live (rn_model_capture / rn_graph_destroy) */
     int chain;               /* fused bf16 mode: conv3 of a 64- / 128-channel block + conv1 of the next block as one launch (default on) */
     int t1_ready;            /* the previous block's chained launch has produced this block's conv1 output */
     int stem_pool;           /* fused mode: stem + batch-norm + ReLU + max-pool as one launch (default on) */
@@ -276,6 +277,9 @@ int rn_model_destroy(rn_model *m)
     uint64_t i;
     int c;
     if (!m) return RN_OK;
+    /* a captured graph points into this model's arenas, weights and the scratch of the contexts of
+     * its extra streams, and rn_graph_destroy unpins those contexts: the graphs go first */
+    if (m->graphs_live > 0) return RN_ERR_INVALID;
     if (m->ctx) rn_sync(m->ctx);
     if (m->params) {
         for (i = 0; i < m->n_params; ++i) rn_free(m->ctx, m->params[i].dev);
@@ -537,6 +541,12 @@ int rn_model_contexts(rn_model *m, rn_ctx **out, int cap)
         if (m->ctxn[k] && n < cap) out[n++] = m->ctxn[k];
     return n;
 }
+/* library-internal: rn_model_capture / rn_graph_destroy count the graphs that hold this model */
+void rn_model_graph_ref(rn_model *m, int delta)
+{
+    if (m) m->graphs_live += delta;
+}
+
 int rn_model_set_pair_fusion(rn_model *m, int on)
 {
     if (!m) return RN_ERR_INVALID;
@@ -547,7 +557,12 @@ int rn_model_set_pair_fusion(rn_model *m, int on)
 
 int rn_model_set_streams(rn_model *m, int streams)
 {
-    if (!m || (streams != 1 && streams != 2 && streams != 4)) return RN_ERR_INVALID;
+    if (!m || (streams != 0 && streams != 1 && streams != 2 && streams != 4)) return RN_ERR_INVALID;
+    if (streams == 0) { /* back to the library default, as if this function had never been called */
+        m->streams = 2;
+        m->streams_set = 0;
+        return RN_OK;
+    }
     m->streams = streams;
     m->streams_set = 1;
     /* the tuned tiles are looked up by launch batch size: those of other part sizes simply stop matching */
@@ -570,7 +585,7 @@ int rn_model_set_stem_pool_fusion(rn_model *m, int on)
 int rn_model_set_chain(rn_model *m, int on)
 {
     if (!m) return RN_ERR_INVALID;
-    m->chain = on < 0 ? 0 : on > 2 ? 2 : on; /* 2: also the streamed-panel chain of stage 3 (slower than its two launches) */
+    m->chain = on ? 1 : 0;
     return RN_OK;
 }
 
@@ -788,12 +803,10 @@ static int chain_applies(const rn_model *m, const rn_block *b, int mode)
     if (c3->k != 1 || c3->stride != 1 || n1->k != 1 || n1->stride != 1 || n1->cin != c3->cout) return 0;
     if (c3->cin == 64 && c3->cout == 256) return n1->cout == 64 || n1->cout == 128;
     if (m->dtype != RN_DTYPE_BF16 || b->ds >= 0) return 0;
-    /* bf16: the 128-channel blocks of stage 2 (panels in registers); the 256-channel blocks of stage 3
-     * have a chain kernel too (panels streamed through LDS, rn_chain_wide.hip), but it measures 112 us
-     * against 91-95 for its two launches (the 64-KB ring holds less than one fetch latency of weights):
-     * only on request (rn_model_set_chain(m, 2)) */
-    return (c3->cin == 128 && c3->cout == 512 && n1->cout == 128) ||
-           (m->chain >= 2 && c3->cin == 256 && c3->cout == 1024 && n1->cout == 256);
+    /* bf16: the 128-channel blocks of stage 2 (panels in registers).  A chain for the 256-channel
+     * blocks of stage 3 (panels streamed through LDS) was built in round 3 and measured 112 us against
+     * 91-95 for its two launches (profiles/round3/chain_against_two_launches_bf16.txt): removed */
+    return c3->cin == 128 && c3->cout == 512 && n1->cout == 128;
 }
 
 static int op_chain(rn_model *m, const rn_block *b, const void *t2, const void *shortcut, void *y,
@@ -1279,4 +1292,80 @@ int rn_model_tune(rn_model *m, const float *input_nchw, uint64_t B, float *logit
     m->tuned_mode = mode;
     /* leave the buffers and the logits as a normal forward would */
     return rn_model_forward(m, input_nchw, B_all, logits, mode);
+}
+
+/* ---- tuned tiles as data ----------------------------------------------------------------
+ * The table rn_model_tune fills, as words: a header that names what it was measured for, then
+ * per convolution and per fused pair the two (tile, launch batch) slots.  A model of the same
+ * architecture, element type and fusion settings on an identical device takes it over instead of
+ * timing every candidate again: the shards of a node (rn_shard_tune tunes ONE shard), or a later
+ * process.  Tiles only change speed, never bits, so a stale table costs time, not parity. */
+#define RN_TUNING_MAGIC 0x726e54554e453034ull /* "rnTUNE04" */
+#define RN_TUNING_HEADER 10
+
+static uint64_t tuning_settings(const rn_model *m)
+{
+    return (uint64_t)m->pair_fusion | (uint64_t)m->stem_exact << 1 | (uint64_t)m->stem_pool << 2 |
+           (uint64_t)m->chain << 4 | (uint64_t)m->front_parts << 8;
+}
+
+int rn_model_export_tuning(const rn_model *m, uint64_t *words, uint64_t cap, uint64_t *n_words)
+{
+    uint64_t need, at = 0;
+    int c, k;
+    if (!m || !n_words) return RN_ERR_INVALID;
+    need = RN_TUNING_HEADER + 4 * ((uint64_t)m->n_convs + (uint64_t)m->n_blocks);
+    *n_words = need;
+    if (!words) return RN_OK; /* size query */
+    if (cap < need || !m->tuned_B) return RN_ERR_INVALID;
+    words[at++] = RN_TUNING_MAGIC;
+    words[at++] = (uint64_t)m->arch;
+    words[at++] = (uint64_t)m->dtype;
+    words[at++] = tuning_settings(m);
+    words[at++] = m->tuned_B;
+    words[at++] = (uint64_t)m->tuned_mode;
+    words[at++] = (uint64_t)m->n_convs;
+    words[at++] = (uint64_t)m->n_blocks;
+    words[at++] = (uint64_t)rn_conv_tile_candidates();
+    words[at++] = 0;
+    for (c = 0; c < m->n_convs; ++c)
+        for (k = 0; k < 2; ++k) {
+            words[at++] = (uint64_t)m->convs[c].tile[k];
+            words[at++] = m->convs[c].tile_B[k];
+        }
+    for (c = 0; c < m->n_blocks; ++c)
+        for (k = 0; k < 2; ++k) {
+            words[at++] = (uint64_t)m->blocks[c].pair_tile[k];
+            words[at++] = m->blocks[c].pair_tile_B[k];
+        }
+    return RN_OK;
+}
+
+int rn_model_import_tuning(rn_model *m, const uint64_t *words, uint64_t n_words)
+{
+    uint64_t at = RN_TUNING_HEADER;
+    int c, k;
+    if (!m || !words || n_words < RN_TUNING_HEADER) return RN_ERR_INVALID;
+    if (words[0] != RN_TUNING_MAGIC || words[1] != (uint64_t)m->arch || words[2] != (uint64_t)m->dtype ||
+        words[3] != tuning_settings(m) || words[6] != (uint64_t)m->n_convs || words[7] != (uint64_t)m->n_blocks ||
+        words[8] != (uint64_t)rn_conv_tile_candidates() ||
+        n_words != RN_TUNING_HEADER + 4 * ((uint64_t)m->n_convs + (uint64_t)m->n_blocks))
+        return RN_ERR_INVALID; /* measured for another model, setting or build */
+    for (c = 0; c < m->n_convs + m->n_blocks; ++c) /* a candidate this build does not have */
+        if (words[at + 4 * (uint64_t)c] > (uint64_t)rn_conv_tile_candidates() ||
+            words[at + 4 * (uint64_t)c + 2] > (uint64_t)rn_conv_tile_candidates())
+            return RN_ERR_INVALID;
+    for (c = 0; c < m->n_convs; ++c)
+        for (k = 0; k < 2; ++k) {
+            m->convs[c].tile[k] = (int)words[at++];
+            m->convs[c].tile_B[k] = words[at++];
+        }
+    for (c = 0; c < m->n_blocks; ++c)
+        for (k = 0; k < 2; ++k) {
+            m->blocks[c].pair_tile[k] = (int)words[at++];
+            m->blocks[c].pair_tile_B[k] = words[at++];
+        }
+    m->tuned_B = words[4];
+    m->tuned_mode = (int)words[5];
+    return RN_OK;
 }

@@ -9,6 +9,7 @@
 
 struct rn_graph {
     rn_ctx *ctx;
+    rn_model *model;  // counted in the model: rn_model_destroy refuses while a graph of it lives
     rn_ctx *pinned[8];  // every context the model queued batch parts on: pinned while the graph lives
     int n_pinned;
     hipGraph_t graph;
@@ -43,6 +44,7 @@ rn_ctx *rn_model_context(rn_model *m);
 int rn_model_profiling_enabled(const rn_model *m);
 // the contexts the model has queued batch parts on so far (rn_model.c)
 int rn_model_contexts(rn_model *m, rn_ctx **out, int cap);
+void rn_model_graph_ref(rn_model *m, int delta);
 
 int rn_graph_destroy(rn_graph *g)
 {
@@ -50,7 +52,10 @@ int rn_graph_destroy(rn_graph *g)
     if (g->ctx) (void)hipStreamSynchronize(g->ctx->stream);
     if (g->exec) {
         (void)hipGraphExecDestroy(g->exec);
+        // the pinned contexts are alive: those of the model's extra streams belong to the model, and
+        // the model cannot be destroyed while this graph is counted in it
         for (int i = 0; i < g->n_pinned; ++i) --g->pinned[i]->graphs_live;
+        if (g->n_pinned) rn_model_graph_ref(g->model, -1);
     }
     if (g->graph) (void)hipGraphDestroy(g->graph);
     free(g);
@@ -95,6 +100,8 @@ int rn_model_capture(rn_model *m, const float *input_nchw, uint64_t B, float *lo
     // into the scratch of the primary context AND of the contexts of the other batch parts
     g->n_pinned = rn_model_contexts(m, g->pinned, 8);
     for (int i = 0; i < g->n_pinned; ++i) ++g->pinned[i]->graphs_live;
+    g->model = m;
+    rn_model_graph_ref(m, +1);
     e = hipGraphGetNodes(g->graph, nullptr, &g->nodes);
     if (e != hipSuccess) {
         rn_graph_destroy(g);
@@ -196,10 +203,21 @@ int rn_pipeline_submit_n(rn_pipeline *p, const float *host_input_nchw, uint64_t 
         return rn_set_error(ctx, RN_ERR_INVALID, "rn_pipeline_submit: both slots busy, collect first");
     rn_pipeline_slot *s = &p->slot[p->head & 1];
     const size_t in_bytes = (size_t)n * 3 * 224 * 224 * sizeof(float);
-    if (host_input_nchw && host_input_nchw != s->h_in)
-        memcpy(s->h_in, host_input_nchw, in_bytes);  // pageable -> pinned
     const int st = [&]() -> int {
-        RN_HIP_TRY(ctx, hipMemcpyAsync(s->d_in, s->h_in, in_bytes, hipMemcpyHostToDevice, p->copy_stream));
+        if (host_input_nchw && host_input_nchw != s->h_in) {
+            // pageable -> pinned -> device in pieces of 16 images (9.6 MB): the upload of piece i runs on the
+            // copy stream while this thread copies piece i+1, so a batch costs max(copy, upload) instead of
+            // their sum before its forward can start (a 154 MB fp32 batch: ~4 ms each)
+            const size_t piece = (size_t)16 * 3 * 224 * 224 * sizeof(float);
+            for (size_t at = 0; at < in_bytes; at += piece) {
+                const size_t nb = in_bytes - at < piece ? in_bytes - at : piece;
+                memcpy((char *)s->h_in + at, (const char *)host_input_nchw + at, nb);
+                RN_HIP_TRY(ctx, hipMemcpyAsync((char *)s->d_in + at, (char *)s->h_in + at, nb, hipMemcpyHostToDevice,
+                                               p->copy_stream));
+            }
+        } else {
+            RN_HIP_TRY(ctx, hipMemcpyAsync(s->d_in, s->h_in, in_bytes, hipMemcpyHostToDevice, p->copy_stream));
+        }
         RN_HIP_TRY(ctx, hipEventRecord(s->uploaded, p->copy_stream));
         // forward on the compute stream once the upload has landed; the other slot's forward may
         // still be running there, which is exactly the overlap

@@ -13,7 +13,9 @@
  * The same device may be listed more than once (two shards on device 0): that is how the
  * sharding code is exercised on a one-GPU box.
  */
+#define _GNU_SOURCE /* pthread_setaffinity_np, CPU_SET */
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,7 +26,7 @@
 #define RN_CLASSES 1000
 
 enum { JOB_NONE = 0, JOB_CREATE, JOB_SET_TENSOR, JOB_LOAD_DIR, JOB_SET_DTYPE, JOB_FINALIZE,
-       JOB_FORWARD, JOB_TUNE, JOB_STREAM_OPEN, JOB_SUBMIT, JOB_COLLECT, JOB_STREAM_CLOSE, JOB_QUIT };
+       JOB_FORWARD, JOB_TUNE, JOB_TUNE_REST, JOB_STREAM_OPEN, JOB_SUBMIT, JOB_COLLECT, JOB_STREAM_CLOSE, JOB_QUIT };
 
 /* A shard's images go through the device in chunks of at most this many: the upload of chunk
  * i+1 (pinned staging, copy stream) runs beside the forward of chunk i (rn_pipeline_*).  Measured
@@ -49,6 +51,8 @@ typedef struct rn_shard_worker {
     int pipe_mode;
     uint64_t stream_lo, stream_hi; /* streaming form: this shard's image range of every batch */
     uint64_t seen; /* last job sequence number this worker ran */
+    int numa_node;     /* of the device's PCI slot, -1 = unknown */
+    char cpus[256];    /* the cores this thread was bound to, "" = not bound */
     int status;
     char err[512];
 } rn_shard_worker;
@@ -68,6 +72,8 @@ struct rn_shard {
     float *logits;
     uint64_t *top1;
     int ivalue; /* dtype or mode */
+    uint64_t *tuning;     /* rn_shard_tune: shard 0's table on its way to the others */
+    uint64_t tuning_words, tuning_nb; /* its size; the launch batch it was measured at */
     uint64_t stream_B;    /* streaming form: batch size of rn_shard_stream_open, 0 = closed */
     int stream_in_flight; /* batches submitted and not yet collected (0..2) */
     char err[640];
@@ -139,11 +145,83 @@ static int collect_chunk(rn_shard_worker *w, const struct rn_shard *g, uint64_t 
     return RN_OK;
 }
 
+/* the launch batch rn_shard_tune measures for on this shard: with a stream open a whole shard per
+ * launch (rn_shard_submit), otherwise the chunks rn_shard_forward issues */
+static uint64_t tune_batch(const rn_shard_worker *w, const struct rn_shard *g)
+{
+    uint64_t lo, hi, nb;
+    rn_shard_bounds(g->numel, w->rank, g->n, &lo, &hi);
+    nb = hi - lo;
+    if (g->stream_B == 0 && nb > RN_SHARD_CHUNK) nb = RN_SHARD_CHUNK;
+    return nb;
+}
+
+/* "0-3,8,10-11" -> cpu set; returns the number of CPUs named */
+static int parse_cpulist(const char *text, cpu_set_t *set)
+{
+    int n = 0;
+    const char *p = text;
+    CPU_ZERO(set);
+    while (*p) {
+        char *end;
+        long a = strtol(p, &end, 10), b;
+        if (end == p) break;
+        b = a;
+        if (*end == '-') {
+            p = end + 1;
+            b = strtol(p, &end, 10);
+            if (end == p) break;
+        }
+        for (; a <= b && a < CPU_SETSIZE; ++a) {
+            if (a >= 0) {
+                CPU_SET((int)a, set);
+                ++n;
+            }
+        }
+        p = *end == ',' ? end + 1 : end;
+        if (*end != ',' ) break;
+    }
+    return n;
+}
+
+/* bind this worker's thread to the cores local to its device that the process may use (best effort) */
+static void bind_near_device(rn_shard_worker *w)
+{
+    char local[256] = {0};
+    cpu_set_t near_set, allowed, both;
+    const char *off = getenv("RN_SHARD_AFFINITY");
+    int cpu, n = 0, first = -1, last = -1;
+    size_t at = 0;
+    w->numa_node = -1;
+    w->cpus[0] = 0;
+    if (rn_device_locality(w->device, NULL, 0, &w->numa_node, local, sizeof(local)) != RN_OK) return;
+    if ((off && off[0] == '0') || !local[0] || parse_cpulist(local, &near_set) == 0) return;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+    CPU_AND(&both, &near_set, &allowed);
+    if (CPU_COUNT(&both) == 0) return; /* the process was confined elsewhere: leave it there */
+    if (pthread_setaffinity_np(pthread_self(), sizeof(both), &both) != 0) return;
+    /* what it got, as a list of ranges */
+    for (cpu = 0; cpu <= CPU_SETSIZE; ++cpu) {
+        const int in = cpu < CPU_SETSIZE && CPU_ISSET(cpu, &both);
+        if (in && first < 0) first = cpu;
+        if (in) last = cpu;
+        if (!in && first >= 0) {
+            int k = snprintf(w->cpus + at, sizeof(w->cpus) - at, first == last ? "%s%d" : "%s%d-%d", n ? "," : "",
+                             first, last);
+            if (k < 0 || (size_t)k >= sizeof(w->cpus) - at) break;
+            at += (size_t)k;
+            ++n;
+            first = -1;
+        }
+    }
+}
+
 static int run_job(rn_shard_worker *w, const struct rn_shard *g)
 {
     switch (g->kind) {
     case JOB_CREATE:
         WTRY(w, rn_ctx_create(&w->ctx, w->device, NULL));
+        bind_near_device(w);
         WTRY(w, rn_model_create(w->ctx, &w->model, g->arch));
         return RN_OK;
     case JOB_SET_TENSOR:
@@ -158,17 +236,24 @@ static int run_job(rn_shard_worker *w, const struct rn_shard *g)
     case JOB_FINALIZE:
         WTRY(w, rn_model_finalize(w->model));
         return RN_OK;
-    case JOB_TUNE: {
-        uint64_t lo, hi, nb;
-        rn_shard_bounds(g->numel, w->rank, g->n, &lo, &hi);
-        nb = hi - lo;
-        if (nb > RN_SHARD_CHUNK) nb = RN_SHARD_CHUNK; /* the launches rn_shard_forward issues */
-        if (nb == 0) return RN_OK;
-        WTRY(w, ensure_buffers(w, nb));
-        WTRY(w, rn_memcpy_h2d(w->ctx, w->d_in, g->tensor + lo * IMG_FLOATS,
-                              nb * IMG_FLOATS * sizeof(float)));
-        WTRY(w, rn_model_tune(w->model, w->d_in, nb, w->d_logits, g->ivalue));
-        WTRY(w, rn_sync(w->ctx));
+    case JOB_TUNE:
+    case JOB_TUNE_REST: {
+        /* JOB_TUNE: shard 0 measures alone (a second shard on the same device, or on the same host
+         * memory path, would be in its timings); JOB_TUNE_REST: the others take its table over when
+         * their share is the same, and measure for themselves when it is not (uneven split) */
+        const uint64_t nb = tune_batch(w, g);
+        if ((g->kind == JOB_TUNE) != (w->rank == 0) || nb == 0) return RN_OK;
+        if (g->kind == JOB_TUNE_REST && g->tuning && nb == g->tuning_nb &&
+            rn_model_import_tuning(w->model, g->tuning, g->tuning_words) == RN_OK)
+            return RN_OK;
+        {
+            uint64_t lo, hi;
+            rn_shard_bounds(g->numel, w->rank, g->n, &lo, &hi);
+            WTRY(w, ensure_buffers(w, nb));
+            WTRY(w, rn_memcpy_h2d(w->ctx, w->d_in, g->tensor + lo * IMG_FLOATS, nb * IMG_FLOATS * sizeof(float)));
+            WTRY(w, rn_model_tune(w->model, w->d_in, nb, w->d_logits, g->ivalue));
+            WTRY(w, rn_sync(w->ctx));
+        }
         return RN_OK;
     }
     case JOB_FORWARD: {
@@ -304,6 +389,7 @@ int rn_shard_destroy(rn_shard *g)
         }
         free(g->w);
     }
+    free(g->tuning);
     pthread_cond_destroy(&g->cv_done);
     pthread_cond_destroy(&g->cv_job);
     pthread_mutex_destroy(&g->mu);
@@ -415,7 +501,48 @@ int rn_shard_forward(rn_shard *g, const float *host_input_nchw, uint64_t B, floa
 
 int rn_shard_tune(rn_shard *g, const float *host_input_nchw, uint64_t B, int mode)
 {
-    return forward_like(g, JOB_TUNE, host_input_nchw, B, NULL, NULL, mode);
+    int st;
+    if (g && g->stream_in_flight > 0) {
+        snprintf(g->err, sizeof(g->err), "rn_shard_tune: %d submitted batch(es) in flight: collect them first",
+                 g->stream_in_flight);
+        return RN_ERR_INVALID;
+    }
+    if (g && g->stream_B != 0 && B != g->stream_B) {
+        snprintf(g->err, sizeof(g->err), "rn_shard_tune: the open stream runs batches of %llu images, not %llu",
+                 (unsigned long long)g->stream_B, (unsigned long long)B);
+        return RN_ERR_INVALID;
+    }
+    st = forward_like(g, JOB_TUNE, host_input_nchw, B, NULL, NULL, mode); /* shard 0 measures */
+    if (st != RN_OK) return st;
+    /* its table, read from this thread while the workers are parked */
+    free(g->tuning);
+    g->tuning = NULL;
+    g->tuning_words = 0;
+    g->tuning_nb = tune_batch(&g->w[0], g);
+    if (g->n > 1 && rn_model_export_tuning(g->w[0].model, NULL, 0, &g->tuning_words) == RN_OK) {
+        g->tuning = (uint64_t *)malloc(g->tuning_words * sizeof(uint64_t));
+        if (g->tuning &&
+            rn_model_export_tuning(g->w[0].model, g->tuning, g->tuning_words, &g->tuning_words) != RN_OK) {
+            free(g->tuning);
+            g->tuning = NULL;
+        }
+    }
+    st = g->n > 1 ? post(g, JOB_TUNE_REST) : RN_OK;
+    free(g->tuning);
+    g->tuning = NULL;
+    return st;
+}
+
+/* between calls on the group the workers are parked: shard `rank`'s model for settings and queries */
+rn_model *rn_shard_model(rn_shard *g, int rank) { return g && rank >= 0 && rank < g->n ? g->w[rank].model : NULL; }
+
+int rn_shard_placement(const rn_shard *g, int rank, int *device, int *numa_node, char *cpulist, uint64_t cpulist_cap)
+{
+    if (!g || rank < 0 || rank >= g->n) return RN_ERR_INVALID;
+    if (device) *device = g->w[rank].device;
+    if (numa_node) *numa_node = g->w[rank].numa_node;
+    if (cpulist && cpulist_cap) snprintf(cpulist, (size_t)cpulist_cap, "%s", g->w[rank].cpus);
+    return RN_OK;
 }
 
 /* ---- streaming form: consecutive batches of B images, two in flight per device ---------- */

@@ -261,6 +261,23 @@ class NativeModel:
                                       L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS),
                 "rn_model_tune", self.ctx.handle)
 
+    def export_tuning(self) -> np.ndarray:
+        """The tile table of the last tune() as uint64 words (rn_model_export_tuning): for a model of the
+        same architecture, element type and settings on an identical device, or a later process."""
+        n = ctypes.c_uint64()
+        L.check(L.lib().rn_model_export_tuning(self.handle, None, 0, ctypes.byref(n)), "rn_model_export_tuning")
+        words = np.zeros(n.value, dtype=np.uint64)
+        L.check(L.lib().rn_model_export_tuning(self.handle, words.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                               n.value, ctypes.byref(n)), "rn_model_export_tuning: not tuned")
+        return words
+
+    def import_tuning(self, words: np.ndarray) -> None:
+        """Take over another model's tile table; refused (RnError) when it was measured for another
+        architecture, element type, fusion setting or build.  Tiles change speed only."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        L.check(L.lib().rn_model_import_tuning(self.handle, words.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                               words.size), "rn_model_import_tuning: table of another model or build")
+
     def set_pair_fusion(self, on: bool) -> None:
         """Fused mode: conv3 + downsample of a stage's first block as one contraction (default
         on) or as two launches with the downsample tensor as the residual."""
@@ -282,8 +299,7 @@ class NativeModel:
     def set_chain(self, on: bool) -> None:
         """Fused mode: conv3 of a bottleneck block + conv1 of the next block as one launch wherever
         a chain kernel exists (fp32: the 64-channel blocks of stage 1; bf16: those and the
-        128-channel blocks of stage 2; rn_model.c chain_applies).  Default on; 2 also chains the
-        256-channel blocks of stage 3 (bf16; measured slower than their two launches).  The same bits
+        128-channel blocks of stage 2; rn_model.c chain_applies).  Default on.  The same bits
         whatever the setting."""
         L.check(L.lib().rn_model_set_chain(self.handle, int(on)), "rn_model_set_chain")
 
@@ -323,7 +339,9 @@ class NativeModel:
 
     def close(self) -> None:
         if self.handle:
-            L.lib().rn_model_destroy(self.handle)
+            # refused (nothing freed) while a graph captured from this model lives: close those first
+            L.check(L.lib().rn_model_destroy(self.handle), "rn_model_destroy: graphs captured from the model "
+                    "are still alive")
             self.handle = None
 
     def __del__(self):
@@ -390,6 +408,24 @@ class ShardedModel:
         self._check(L.lib().rn_shard_tune(self.handle, x.ctypes.data, x.shape[0],
                                           L.RN_FWD_FUSED if fused else L.RN_FWD_REFERENCE_OPS),
                     "rn_shard_tune")
+
+    def tuning_of(self, rank: int) -> np.ndarray:
+        """The tile table shard `rank` runs with (rn_shard_model + rn_model_export_tuning)."""
+        lib = L.lib()
+        mh = lib.rn_shard_model(self.handle, rank)
+        n = ctypes.c_uint64()
+        self._check(lib.rn_model_export_tuning(mh, None, 0, ctypes.byref(n)), "rn_model_export_tuning")
+        words = np.zeros(n.value, dtype=np.uint64)
+        self._check(lib.rn_model_export_tuning(mh, words.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), n.value,
+                                               ctypes.byref(n)), "rn_model_export_tuning: shard not tuned")
+        return words
+
+    def placement(self, rank: int):
+        """(device, NUMA node of the device's slot or -1, the CPUs shard `rank`'s host thread is bound to or '')."""
+        dev, node, buf = ctypes.c_int(), ctypes.c_int(), ctypes.create_string_buffer(256)
+        self._check(L.lib().rn_shard_placement(self.handle, rank, ctypes.byref(dev), ctypes.byref(node), buf, 256),
+                    "rn_shard_placement")
+        return dev.value, node.value, buf.value.decode()
 
     # streaming form: consecutive batches of B images, two in flight on every device
     def stream_open(self, B: int, fused: bool = True) -> None:

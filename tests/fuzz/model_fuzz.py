@@ -50,7 +50,7 @@ def main():
             elif op == "front":
                 m.set_front_parts(int(g.choice([1, 2, 4, 8])))
             elif op == "chain":
-                m.set_chain(int(g.choice([0, 1, 2])))
+                m.set_chain(int(g.choice([0, 1])))
             elif op == "tune":
                 B = int(g.choice([4, 32, 100, 128, 256]))
                 xin = R.FloatTensor.from_numpy(pool[:B], R.Device.GPU)

@@ -229,17 +229,14 @@ def test_strip_kernel_full_size_under_load():
 
 
 @pytest.mark.parametrize("case", [(3, 20, 20, 64, 64), (1, 8, 8, 64, 64), (2, 56, 56, 64, 128), (5, 13, 9, 64, 128),
-                                  (2, 28, 28, 128, 128), (3, 9, 7, 128, 128), (1, 4, 8, 128, 128),
-                                  (4, 14, 14, 256, 256), (3, 9, 7, 256, 256), (1, 2, 3, 256, 256), (2, 16, 16, 256, 256)])
+                                  (2, 28, 28, 128, 128), (3, 9, 7, 128, 128), (1, 4, 8, 128, 128)])
 def test_conv_chain_is_the_two_separate_launches_bit_for_bit(case):
     """rn_conv_chain_forward_dt (conv3 + bn3 + residual + ReLU of a block, conv1 + bn1 + ReLU of the
     next, y through LDS) against the two rn_conv2d_nhwc_forward_dt calls it replaces: y and t1 bit
     for bit -- same k order, same epilogue expression, y rounded to bf16 before conv1 multiplies
     it -- and y against the oracle.  64 mid channels (8 waves, 64-row steps; both widths of the
     next block's conv1) and 128 (4 waves with 448 registers each, 32-row steps); ragged last
-    steps (1200, 585 and 189 rows), one-step launches.  256 mid channels (stage 3: 128-row blocks,
-    both weight panels streamed through an LDS ring, rn_chain_wide.hip): whole blocks (784, 512
-    rows), a ragged last block (189 rows), a block of six rows."""
+    steps (1200, 585 and 189 rows), one-step launches."""
     B, H, W, MID, N1 = case
     C = 4 * MID
     seed = 700 + sum(case)

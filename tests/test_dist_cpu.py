@@ -33,6 +33,13 @@ def _worker(rank, world, port, q):
     y = O.conv2d(x.astype(np.float32), w, 1, 1).reshape(hi - lo, -1).sum(1)
     bench.barrier(world)
     t = bench.max_over_ranks(1.0 + rank, world)
+    # the per-rank records of the bench line's `world` block: every rank's own time next to the max
+    me = {"rank": rank, "local_rank": rank, "device_index": rank, "device": f"cpu{rank}", "pid": os.getpid(),
+          "ms_per_step": 10.0 + 5.0 * rank, "images_per_s": 256e3 / (10.0 + 5.0 * rank)}
+    wb = bench.world_block(bench.gather_ranks(me, world), dist.get_world_size(), dist.get_backend())
+    assert wb["size"] == world and wb["backend"] == "gloo" and [r["rank"] for r in wb["ranks"]] == [0, 1]
+    assert [r["ms_per_step"] for r in wb["ranks"]] == [10.0, 15.0] and wb["ranks"][rank]["pid"] == os.getpid()
+    assert (wb["slowest_rank"], wb["slowest_rank_ms_per_step"], wb["fastest_rank_ms_per_step"]) == (1, 15.0, 10.0)
     gathered = [torch.zeros(per_gpu, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(gathered, torch.from_numpy(y.astype(np.float64)))
     q.put((rank, lo, hi, t, torch.cat(gathered).numpy()))

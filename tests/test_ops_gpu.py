@@ -239,6 +239,7 @@ def test_maxpool_all_padding_window_and_nan():
                                    # NCHW, small planes and a batch to walk (one image position per lane):
                                    (16, 512, 7, 7), (9, 256, 14, 14), (8, 3, 16, 16), (12, 7, 2, 2), (64, 33, 3, 4)])
 def test_batchnorm_matches_double_expression(shape, layout):
+    """ops.cu:150 type by type (fp32 subtraction, then double, one rounding): the same bits as the oracle."""
     g = np.random.default_rng(sum(shape))
     x = g.standard_normal(shape, dtype=np.float32) * 3
     C = shape[1]
@@ -246,10 +247,37 @@ def test_batchnorm_matches_double_expression(shape, layout):
     m, v = g.standard_normal(C, dtype=np.float32), g.random(C, dtype=np.float32) + 0.5
     want = O.batchnorm2d(x, w, b, m, v)
     got = ops.batchnorm2d(x, w, b, m, v, layout, inplace=True)  # in place, like main.cu:138
-    ulp = np.spacing(np.abs(want).astype(np.float32))
-    assert (np.abs(got - want) <= ulp).all()
-    assert (got != want).mean() < 1e-3  # double-rounding differences are rare
+    assert np.array_equal(got, want)
     assert np.array_equal(ops.batchnorm2d(x, w, b, m, v, layout, inplace=False), got)
+
+
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_batchnorm_special_values_follow_the_reference_expression(layout):
+    """Infinite / NaN / huge inputs, a zero and a negative denominator: what `(x - m) / sqrt(v + 1e-5) * w + b`
+    gives in the reference's types (the Markstein quotient of the kernel must not turn inf into NaN)."""
+    B, C, H, W = 8, 8, 4, 4
+    g = np.random.default_rng(77)
+    x = g.standard_normal((B, C, H, W), dtype=np.float32)
+    x[0, :, 0, 0] = np.inf
+    x[1, :, 0, 1] = -np.inf
+    x[2, :, 1, 0] = np.nan
+    x[3, :, 1, 1] = 3.0e38
+    x[4, :, 2, 2] = -3.0e38
+    x[5, :, 3, 3] = 1e-42      # denormal
+    w, b = g.random(C, dtype=np.float32) + 0.5, g.standard_normal(C, dtype=np.float32)
+    m, v = g.standard_normal(C, dtype=np.float32), g.random(C, dtype=np.float32) + 0.5
+    w[1] = 0.0                 # inf * 0 = NaN
+    w[2] = -1.5
+    v[3] = -1.0                # sqrt of a negative: NaN everywhere in the channel
+    v[4] = np.float32(-1e-5)   # var + 1e-5 in double: the float is not exactly -1e-5, tiny or negative
+    m[5] = np.inf              # x - inf in fp32
+    with np.errstate(all="ignore"):
+        want = O.batchnorm2d(x, w, b, m, v)
+        got = ops.batchnorm2d(x, w, b, m, v, layout, inplace=False)
+    assert np.array_equal(got, want, equal_nan=True)
+    ok = ~np.isnan(want)
+    assert np.array_equal(np.signbit(got[ok]), np.signbit(want[ok]))
+    assert np.isinf(want).any() and np.isnan(want).any()
 
 
 @pytest.mark.parametrize("n", [1, 3, 4, 17, 1023, 1024, 1025, 4099, 1 << 20])
@@ -792,93 +820,6 @@ def test_fused_stem_refuses_what_it_cannot_do():
             with pytest.raises(L.RnError) as e:
                 ops.stem_pool(x, w, None, None, False, bf16=bf16, from_nchw=nchw)
             assert e.value.status == L.RN_ERR_INVALID and "ReLU" in str(e.value)
-
-
-FP32_STRIP_CASES = [(3, 20, 20), (1, 6, 6), (2, 56, 56), (5, 7, 61), (4, 1, 9), (2, 33, 5), (37, 28, 28), (70, 30, 32)]
-
-
-@pytest.mark.parametrize("case", FP32_STRIP_CASES)
-def test_fp32_strip_kernel_matches_oracle_and_the_tile_kernels_bits(case):
-    """conv_strip32_kernel (rn_conv_strip32.hip: fp32, 3x3 / stride 1 / 64 -> 64 channels, weights in
-    registers, the zero-padded image in a rolling LDS ring, operands swapped, stores straight from
-    registers) -- the tuner's last candidate.  Against the
-    oracle and bit for bit against a 64x64 tile of conv_gemm_kernel: the widest image the ring margin
-    allows (61), one-row and narrow images, several images per step, several steps per block
-    (70 x 30 x 32: 558 steps on 256 blocks), with and without the epilogue."""
-    from resnet_c_amd import _lib as L
-    B, H, W = case
-    C = 64
-    x, w = rnd((B, C, H, W), 950 + sum(case)), rnd((C, C, 3, 3), 951 + sum(case)) / np.sqrt(9.0 * C)
-    g = np.random.default_rng(952 + sum(case))
-    sc, sh = g.random(C, dtype=np.float32) + 0.5, g.standard_normal(C, dtype=np.float32)
-    ctx, lib = R.get_ctx(), L.lib()
-    strip = lib.rn_conv_tile_candidates()
-    try:
-        lib.rn_ctx_set_conv_tile(ctx.handle, 4)
-        want_ep = ops.conv2d_nhwc_fused(x, w, 1, 1, sc, sh, None, True)
-        want_plain = ops.conv2d_nhwc_fused(x, w, 1, 1)
-        n0 = lib.rn_ctx_launch_count(ctx.handle)
-        lib.rn_ctx_set_conv_tile(ctx.handle, strip)
-        got_ep = ops.conv2d_nhwc_fused(x, w, 1, 1, sc, sh, None, True)
-        got_plain = ops.conv2d_nhwc_fused(x, w, 1, 1)
-        # a residual is not the strip kernel's business: the call must fall back, same bits
-        res = rnd((B, C, H, W), 953 + sum(case))
-        lib.rn_ctx_set_conv_tile(ctx.handle, 4)
-        want_res = ops.conv2d_nhwc_fused(x, w, 1, 1, sc, sh, res, True)
-        lib.rn_ctx_set_conv_tile(ctx.handle, strip)
-        got_res = ops.conv2d_nhwc_fused(x, w, 1, 1, sc, sh, res, True)
-    finally:
-        lib.rn_ctx_set_conv_tile(ctx.handle, 0)
-    assert np.array_equal(got_ep, want_ep) and np.array_equal(got_plain, want_plain)
-    assert np.array_equal(got_res, want_res)
-    if B * H * W <= 8000:
-        y = O.conv2d(x, w, 1, 1)
-        want = np.maximum(y * sc[None, :, None, None] + sh[None, :, None, None], 0)
-        assert np.abs(got_ep - want).max() <= 2e-6 * np.sqrt(9 * C) * float(np.abs(want).max()) + 1e-6
-        assert np.abs(got_plain - y).max() <= 2e-6 * np.sqrt(9 * C) * float(np.abs(y).max()) + 1e-6
-
-
-def test_fp32_strip_kernel_full_size_under_load():
-    """B = 256 at 56 x 56 fp32: 6,612 steps, 26 per block -- the ring wraps and every slot is rewritten
-    many times while the neighbours are still being read.  Back-to-back runs against the tile kernel's
-    bits (a read that slipped ahead of its DMA would come and go with timing)."""
-    from resnet_c_amd import _lib as L
-    from resnet_c_amd.tensor import _DeviceBuffer
-    ctx, lib = R.get_ctx(), L.lib()
-    B, H, W, C = 256, 56, 56, 64
-    g = np.random.default_rng(78)
-    n_in, n_w = B * H * W * C, C * 9 * C
-    x, w, out = _DeviceBuffer(ctx, n_in * 4), _DeviceBuffer(ctx, n_w * 4), _DeviceBuffer(ctx, n_in * 4)
-    xh = g.standard_normal(n_in, dtype=np.float32)
-    wh = g.standard_normal(n_w, dtype=np.float32) / 24.0
-    L.check(lib.rn_memcpy_h2d(ctx.handle, x.ptr, xh.ctypes.data, xh.nbytes), "h2d", ctx.handle)
-    L.check(lib.rn_memcpy_h2d(ctx.handle, w.ptr, wh.ctypes.data, wh.nbytes), "h2d", ctx.handle)
-    ep = L.Epilogue(None, None, None, 1)
-
-    def run(cand):
-        lib.rn_ctx_set_conv_tile(ctx.handle, cand)
-        L.check(lib.rn_conv2d_nhwc_forward(ctx.handle, x.ptr, out.ptr, w.ptr, 3, 1, 1, H, W, B, C, C, H, W,
-                                           ctypes.byref(ep)), "conv", ctx.handle)
-
-    def fetch():
-        ctx.sync()
-        h = np.empty(n_in, dtype=np.float32)
-        L.check(lib.rn_memcpy_d2h(ctx.handle, h.ctypes.data, out.ptr, h.nbytes), "d2h", ctx.handle)
-        return h
-
-    try:
-        run(6)
-        want = fetch()
-        assert want.any()
-        L.check(lib.rn_memset(ctx.handle, out.ptr, 0xFF, n_in * 4), "memset", ctx.handle)
-        for rep in range(4):
-            for _ in range(3):
-                run(lib.rn_conv_tile_candidates())
-            assert np.array_equal(fetch(), want), rep
-        run(0)                                   # the untuned choice: a tile kernel, the same bits
-        assert np.array_equal(fetch(), want)
-    finally:
-        lib.rn_ctx_set_conv_tile(ctx.handle, 0)
 
 
 @pytest.mark.parametrize("seed", range(8))
