@@ -193,14 +193,12 @@ def cpu_baseline(arch: str, state, seconds_budget: float = 30.0, engine=None, ba
                       f"{os.cpu_count()} host cpus)"}
 
 
-def pmc_traffic(args, launches_per_forward: int):
-    """(HBM bytes per launch of the contraction kernels, file they come from, stale?).  Hardware
-    counters cannot be read from inside this process: the figure is the one of the committed
-    rocprofv3 --pmc passes of this same command (profiles/round*/final_hbm_traffic_pmc*.json, made
-    by tools/pmc_traffic.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950).
-    That file carries the digest of the kernel sources it was measured on and its launch count:
-    when either differs from this build / this run the figure no longer describes what ran, and
-    the line says traffic = null, traffic_stale = true.  Configurations without a file: null."""
+def _committed_pmc(args, launches_per_forward: int, stem: str):
+    """The newest profiles/round*/<stem><config tag>.json when it describes THIS build and THIS graph:
+    (record, file, stale?).  Hardware counters cannot be read from inside this process; the committed
+    rocprofv3 --pmc passes of this same command carry the digest of the kernel sources they were measured
+    on and their launch count, and when either differs from this build / this run the figure no longer
+    describes what ran: (None, file, True).  Configurations without a file: (None, None, False)."""
     if not (args.batch == 256 and args.mode == "fused" and args.arch == "resnet50") and \
             not (args.arch == "resnet152" and args.batch == 128 and args.mode == "fused" and args.dtype == "f32"):
         return None, None, False
@@ -211,7 +209,7 @@ def pmc_traffic(args, launches_per_forward: int):
     tag = "" if args.dtype == "f32" else f"_{args.dtype}"
     if args.arch != "resnet50":
         tag += f"_{args.arch}_b{args.batch}"
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"final_hbm_traffic_pmc{tag}.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", f"{stem}{tag}.json")))
     if not files:
         return None, None, False
     src = os.path.relpath(files[-1], ROOT)
@@ -222,7 +220,31 @@ def pmc_traffic(args, launches_per_forward: int):
         if rec.get("source_digest") != R._lib.source_digest() or \
                 abs(int(rec.get("launches", -100)) - int(launches_per_forward)) > 4:
             return None, src, True
-        return round(rec["traffic_bytes_per_launch"]), src, False
+        return rec, src, False
+    except Exception:
+        return None, src, True
+
+
+def pmc_traffic(args, launches_per_forward: int):
+    """(HBM bytes per launch of the contraction kernels, file they come from, stale?): the committed
+    FETCH_SIZE / WRITE_SIZE passes (profiles/round*/final_hbm_traffic_pmc*.json, tools/pmc_traffic.py:
+    separate passes, FETCH_SIZE x2 on gfx950); traffic = null, traffic_stale = true for any other build."""
+    rec, src, stale = _committed_pmc(args, launches_per_forward, "final_hbm_traffic_pmc")
+    try:
+        return (round(rec["traffic_bytes_per_launch"]) if rec else None), src, stale
+    except Exception:
+        return None, src, True
+
+
+def pmc_mfma_busy(args, launches_per_forward: int):
+    """Matrix-pipe utilisation of the contraction launches from the committed SQ counter pass
+    (profiles/round*/final_pmc_mfma_utilisation*.json, tools/pmc_mfma.py): {mfma_busy, ...}, file, stale?"""
+    rec, src, stale = _committed_pmc(args, launches_per_forward, "final_pmc_mfma_utilisation")
+    try:
+        if rec:
+            rec = {k: rec[k] for k in ("mfma_busy", "mfma_busy_in_busy_cu", "cu_busy", "wait_inst_over_wave_cycles",
+                                       "wait_any_over_wave_cycles", "lds_bank_conflict_over_idx_active")}
+        return rec, src, stale
     except Exception:
         return None, src, True
 
@@ -449,6 +471,7 @@ def main():
     frac_mfma, frac_hbm = achieved / peak, g_gbps / PEAK_HBM_GBS
     bound = "mfma" if frac_mfma >= frac_hbm else "hbm"
     traffic, traffic_source, traffic_stale = pmc_traffic(args, g_launch)
+    busy, busy_source, busy_stale = pmc_mfma_busy(args, g_launch)
     result = {
         "metric": "images/sec ResNet-50 224x224 fp32 batch=256"
                   if args.arch == "resnet50" and B == 256 and args.dtype == "f32"
@@ -481,6 +504,10 @@ def main():
                      "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                      "frac": round(max(frac_mfma, frac_hbm), 4),
                      "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
+                     # share of the chip's SIMD-cycles with a matrix pipe busy during the contraction launches
+                     # (SQ_VALU_MFMA_BUSY_CYCLES; committed --pmc pass of this command, this build only)
+                     "mfma_busy": busy["mfma_busy"] if busy else None,
+                     "mfma_busy_detail": busy, "mfma_busy_source": busy_source, "mfma_busy_stale": busy_stale,
                      "source_digest": R._lib.source_digest(),
                      "kernel": "conv_gemm_kernel" + (" / conv_wide_kernel / conv_strip_kernel / chain_kernel" if args.dtype == "bf16" else " / chain32_kernel") +
                                " (implicit-GEMM conv2d + fc on " +

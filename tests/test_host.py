@@ -180,8 +180,19 @@ def test_bench_quotes_pmc_traffic_only_for_the_build_it_was_measured_on(tmp_path
     (d / "final_hbm_traffic_pmc.json").write_text(json.dumps(rec))
     value, src, stale = bench.pmc_traffic(args, 69)
     assert value is None and stale is True and src.endswith("final_hbm_traffic_pmc.json")
+    # the matrix-pipe utilisation pass is quoted under the same rule
+    busy = {"mfma_busy": 0.71, "mfma_busy_in_busy_cu": 0.83, "cu_busy": 0.9, "wait_inst_over_wave_cycles": 0.6,
+            "wait_any_over_wave_cycles": 0.2, "lds_bank_conflict_over_idx_active": 0.0,
+            "launches": 69, "source_digest": digest}
+    (d / "final_pmc_mfma_utilisation.json").write_text(json.dumps(busy))
+    got, src, stale = bench.pmc_mfma_busy(args, 70)
+    assert got["mfma_busy"] == 0.71 and src.endswith("final_pmc_mfma_utilisation.json") and stale is False
+    busy["source_digest"] = "1" * 16
+    (d / "final_pmc_mfma_utilisation.json").write_text(json.dumps(busy))
+    assert bench.pmc_mfma_busy(args, 70)[0] is None and bench.pmc_mfma_busy(args, 70)[2] is True
     args.dtype = "bf16"                                          # no file for this configuration
     assert bench.pmc_traffic(args, 45) == (None, None, False)
+    assert bench.pmc_mfma_busy(args, 45) == (None, None, False)
     args = argparse.Namespace(arch="resnet101", batch=64, mode="fused", dtype="f32")
     assert bench.pmc_traffic(args, 10) == (None, None, False)
 
@@ -192,7 +203,9 @@ def test_committed_pmc_traffic_is_that_of_the_committed_kernel_sources():
     import glob
     import json
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", "final_hbm_traffic_pmc.json")))
-    assert files
-    rec = json.load(open(files[-1]))
-    assert rec["source_digest"] == L.source_digest(), "re-run tools/evidence.sh pmc and commit profiles/"
+    for stem in ("final_hbm_traffic_pmc", "final_hbm_traffic_pmc_bf16", "final_pmc_mfma_utilisation",
+                 "final_pmc_mfma_utilisation_bf16"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*", stem + ".json")))
+        assert files, stem
+        rec = json.load(open(files[-1]))
+        assert rec["source_digest"] == L.source_digest(), f"{files[-1]}: re-run tools/evidence.sh pmc and commit profiles/"

@@ -1,11 +1,26 @@
 #!/bin/bash
 # gpurun_out/ev (scratch, what tools/evidence.sh wrote on the box) -> profiles/roundN/final_* (tracked)
-#   bash tools/copy_evidence.sh pmc|bench|trace [round dir]
-what=${1:-pmc}; d=${2:-profiles/round3}; o=gpurun_out/ev
+#   bash tools/copy_evidence.sh pmc|mfma|bench|trace [round dir]
+# Refuses a phase whose stamp (digest of the kernel sources it ran on) is not the tree's: evidence of
+# another build must not be committed as HEAD's.
+what=${1:-pmc}; d=${2:-profiles/round4}; o=gpurun_out/ev
+mkdir -p $d
+tree=$(python3 -c "import resnet_c_amd as R; print(R._lib.source_digest())")
+if [ ! -f $o/$what.stamp ] || [ "$(cat $o/$what.stamp)" != "$tree" ]; then
+  echo "copy_evidence: $o/$what.stamp = $(cat $o/$what.stamp 2>/dev/null) but the tree is $tree: not copying" >&2
+  exit 1
+fi
 if [ $what = pmc ]; then
   for pair in "f32:" "bf16:_bf16" "resnet152_b128:_resnet152_b128"; do
     src=$o/hbm_traffic_pmc_${pair%%:*}; dst=$d/final_hbm_traffic_pmc${pair##*:}
     for ext in json per_kernel.txt per_layer.txt; do [ -f $src.$ext ] && cp $src.$ext $dst.$ext; done
+  done
+fi
+if [ $what = mfma ]; then
+  for pair in "f32:" "bf16:_bf16"; do
+    src=$o/pmc_mfma_utilisation_${pair%%:*}
+    [ -f $src.json ] && cp $src.json $d/final_pmc_mfma_utilisation${pair##*:}.json
+    [ -f $src.per_kernel.txt ] && cp $src.per_kernel.txt $d/pmc_mfma_utilisation_per_kernel_${pair%%:*}.txt
   done
 fi
 if [ $what = bench ]; then
@@ -15,8 +30,7 @@ if [ $what = bench ]; then
 fi
 if [ $what = trace ]; then
   for n in f32 bf16 ops_mode resnet152_b128; do
-    for k in kernel_stats_$n.csv timed_region_kernels_$n.json; do [ -f $o/$k ] && cp $o/$k $d/final_$k; done
+    for k in kernel_stats_$n.csv timed_region_kernels_$n.json bench_under_rocprof_$n.json; do [ -f $o/$k ] && cp $o/$k $d/final_$k; done
   done
-  for n in f32 bf16 ops resnet152_b128; do cp $o/bench_under_rocprof_$n.json $d/final_bench_under_rocprof_$n.json; done
 fi
-git status --short $d | head -30
+git status --short $d | head -40

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Matrix-pipe utilisation of the contraction kernels from ONE rocprofv3 --pmc pass
+(SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE: 8 SQ slots; GRBM_GUI_ACTIVE rides in the GRBM block).
+
+    python tools/pmc_mfma.py <pmc dir> out.json <launches per forward> [note]
+
+Uses the contraction dispatches of the LAST forward of the run (as tools/pmc_traffic.py does).  Per kernel
+instantiation and for the family as a whole:
+
+  mfma_busy            SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), kernel cycles =
+                       GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the counter over the 8 XCDs): the share of ALL the
+                       chip's SIMD-cycles during the launches in which a matrix pipe was busy -- times the
+                       clock the chip held, this is what the achieved TFLOP/s is made of;
+  mfma_busy_in_busy_cu SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES): the same inside the CUs that had
+                       a wave (tails and ramps taken out);
+  wait_inst / wait_any SQ_WAIT_INST_ANY, SQ_WAIT_ANY over SQ_WAVE_CYCLES (issue stalls; parked on s_waitcnt or
+                       a barrier), lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.
+
+The JSON carries the digest of the kernel sources (resnet_c_amd._lib.source_digest) and the launch count;
+bench.py quotes roofline.mfma_busy from it only for the build it was measured on.  The per-kernel table goes
+next to it as <out minus .json>.per_kernel.txt.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+FAMILY = ("conv_gemm_kernel", "conv_wide_kernel", "conv_strip_kernel", "conv_strip128_kernel", "chain_kernel",
+          "chain32_", "splitk_finish_kernel", "stem_pool_kernel", "conv1x1_nchw_kernel", "conv_pair_kernel",
+          "conv_fused23_kernel")
+CUS, SIMDS, XCDS = 256, 4, 8
+
+
+def short(name):
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("rn_gemm::", "")
+    return n.split("(")[0][:110]
+
+
+def dispatches(d):
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    by = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        k = int(r["Dispatch_Id"])
+        e = by.setdefault(k, {"name": r["Kernel_Name"], "c": collections.defaultdict(float)})
+        e["c"][r["Counter_Name"]] += float(r["Counter_Value"])
+    return [by[k] for k in sorted(by)]
+
+
+def ratios(c):
+    out = {}
+    cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
+    if cyc > 0:
+        out["mfma_busy"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (SIMDS * CUS * cyc)
+        out["cu_busy"] = c.get("SQ_BUSY_CU_CYCLES", 0.0) / (CUS * cyc)
+    if c.get("SQ_BUSY_CU_CYCLES"):
+        out["mfma_busy_in_busy_cu"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (SIMDS * c["SQ_BUSY_CU_CYCLES"])
+    if c.get("SQ_WAVE_CYCLES"):
+        out["wait_inst"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        out["wait_any"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_conflict"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+    return out
+
+
+def main():
+    d, out_path, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    note = sys.argv[4] if len(sys.argv) > 4 else ""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from resnet_c_amd._lib import source_digest
+
+    rows = [e for e in dispatches(d) if any(k in e["name"] for k in FAMILY)][-n:]
+    total = collections.defaultdict(float)
+    per = collections.OrderedDict()
+    for e in rows:
+        p = per.setdefault(short(e["name"]), {"launches": 0, "c": collections.defaultdict(float)})
+        p["launches"] += 1
+        for k, v in e["c"].items():
+            p["c"][k] += v
+            total[k] += v
+    table = os.path.splitext(out_path)[0] + ".per_kernel.txt"
+    with open(table, "w") as fh:
+        fh.write("# one forward; mfma_busy = MFMA busy cycles / (4 SIMDs x 256 CUs x kernel cycles); in_busy_cu = / (4 x CU-busy cycles)\n")
+        fh.write("launches  kernel_us mfma_busy in_busy_cu cu_busy wait_inst wait_any lds_confl  MFMA insts   kernel instantiation\n")
+        for k, p in sorted(per.items(), key=lambda kv: -kv[1]["c"].get("GRBM_GUI_ACTIVE", 0.0)):
+            r, c = ratios(p["c"]), p["c"]
+            fh.write(f"{p['launches']:8d} {c.get('GRBM_GUI_ACTIVE', 0.0) / XCDS / 2.4e3:10.1f} {r.get('mfma_busy', 0):9.3f} "
+                     f"{r.get('mfma_busy_in_busy_cu', 0):10.3f} {r.get('cu_busy', 0):7.3f} {r.get('wait_inst', 0):9.3f} "
+                     f"{r.get('wait_any', 0):8.3f} {r.get('lds_conflict', 0):9.3f} {c.get('SQ_INSTS_MFMA', 0):12.0f}   {k}\n")
+        fh.write("# kernel_us: GRBM_GUI_ACTIVE / 8 at a nominal 2.4 GHz (the chip holds less under load: durations come from the traces)\n")
+    r = ratios(total)
+    out = {"kernel": " + ".join(FAMILY), "launches": len(rows), "source_digest": source_digest(),
+           "mfma_busy": round(r.get("mfma_busy", 0.0), 4),
+           "mfma_busy_in_busy_cu": round(r.get("mfma_busy_in_busy_cu", 0.0), 4),
+           "cu_busy": round(r.get("cu_busy", 0.0), 4),
+           "wait_inst_over_wave_cycles": round(r.get("wait_inst", 0.0), 4),
+           "wait_any_over_wave_cycles": round(r.get("wait_any", 0.0), 4),
+           "lds_bank_conflict_over_idx_active": round(r.get("lds_conflict", 0.0), 4),
+           "counters": {k: v for k, v in sorted(total.items())},
+           "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8), contraction "
+                         "launches of the last forward of one rocprofv3 --pmc pass",
+           "note": note}
+    json.dump(out, open(out_path, "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("launches", "mfma_busy", "mfma_busy_in_busy_cu", "cu_busy")}))
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,7 @@ for dtype in ("f32", "bf16"):
         g.forward(x, fused=True)
     one_shot = B * a.steps / (time.perf_counter() - t0)
     g.stream_open(B, fused=True)
+    g.tune(x, fused=True)   # with a stream open: the tiles of a whole shard per launch (not of the one-shot form's chunks)
     g.submit(x); g.submit(x); g.collect(); g.collect()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -62,6 +63,7 @@ for dtype in ("f32", "bf16"):
         g.collect()
     stream_inplace = B * a.steps / (time.perf_counter() - t0)
     g.stream_close()
+    g_place = [g.placement(r) for r in range(len(devices))]
     g.close()
     m = R.NativeModel("resnet50", state=state, dtype=dtype)
     xd = R.FloatTensor.from_numpy(x[:a.batch], R.Device.GPU)
@@ -76,6 +78,8 @@ for dtype in ("f32", "bf16"):
     m.ctx.sync()
     resident = a.batch * a.steps / (time.perf_counter() - t0)
     m.close()
+    print(f"{dtype} placement: " + "; ".join("shard %d on device %d, NUMA node %d, cpus [%s]" % ((r,) + g_place[r])
+                                              for r in range(len(devices))))
     print(f"{dtype} devices {devices} B={B}: one-shot {one_shot:9.0f}  stream/copy {stream_copy:9.0f}  "
           f"stream/inplace {stream_inplace:9.0f}  img/s with upload + download;  resident (one device) {resident:9.0f} img/s",
           flush=True)
