@@ -1,7 +1,9 @@
 // rn/nn.hpp -- layer wrappers with the reference's class and member names
 // (cuda/nn.cuh:8-136): Conv2d, BatchNorm2d, Pool2d, Linear, reluForward, addForward.
 // forward(x, out) never allocates and runs in the layout of x (NCHW unless the
-// caller tagged the tensor NHWC); one C-ABI call per forward.
+// caller tagged the tensor NHWC); one C-ABI call per forward.  The veneer's context is
+// deferred (rn_ctx_set_deferred): those calls are recorded and run when a result is
+// observed, a convolution together with the in-place batch-norm / add / ReLU behind it.
 #ifndef RN_NN_HPP
 #define RN_NN_HPP
 
@@ -57,7 +59,7 @@ public:
         (void)C, (void)ob, (void)oc;
         rn::use_layout(x);
         out.layout = x.layout;
-        conv2dForwardKernel(x.data(), out.data(), weight.data(), kernel_size, stride, padding, h_out,
+        conv2dForwardKernel(x.raw(), out.raw(), weight.raw(), kernel_size, stride, padding, h_out,
                             w_out, B, in_channels, out_channels, H, W);
     }
 
@@ -92,8 +94,8 @@ public:
         (void)C;
         rn::use_layout(x);
         out.layout = x.layout;
-        batchNorm2dForwardKernel(x.data(), out.data(), weight.data(), bias.data(), mean.data(),
-                                 var.data(), B, channels_num, h * w);
+        batchNorm2dForwardKernel(x.raw(), out.raw(), weight.raw(), bias.raw(), mean.raw(), var.raw(), B,
+                                 channels_num, h * w);
     }
 
     FloatTensor weight, bias, mean, var;
@@ -131,7 +133,7 @@ private:
         rn::use_layout(x);
         out.layout = x.layout;
         auto *fn = is_max ? maxPool2dKernel : avgPool2dKernel;
-        fn(x.data(), out.data(), kernel_size, stride, padding, out.shape().at(2), out.shape().at(3), B,
+        fn(x.raw(), out.raw(), kernel_size, stride, padding, out.shape().at(2), out.shape().at(3), B,
            C, H, W);
     }
 };
@@ -160,7 +162,7 @@ public:
 
     void forward(FloatTensor &x, FloatTensor &out)
     {
-        linearForwardKernel(x.data(), out.data(), weight.data(), bias.data(), x.shape().at(0),
+        linearForwardKernel(x.raw(), out.raw(), weight.raw(), bias.raw(), x.shape().at(0),
                             in_features, out_features);
     }
 
@@ -172,14 +174,14 @@ inline void reluForward(FloatTensor &x, FloatTensor &out)
 {
     rn::require(x.shape() == out.shape());
     out.layout = x.layout;
-    reluForwardKernel(x.data(), out.data(), x.numel());
+    reluForwardKernel(x.raw(), out.raw(), x.numel());
 }
 
 inline void addForward(FloatTensor &a, FloatTensor &b, FloatTensor &out)
 {
     rn::require(a.shape() == b.shape() && a.shape() == out.shape() && a.layout == b.layout);
     out.layout = a.layout;
-    addForwardKernel(a.data(), b.data(), out.data(), a.numel());
+    addForwardKernel(a.raw(), b.raw(), out.raw(), a.numel());
 }
 
 #endif  // RN_NN_HPP

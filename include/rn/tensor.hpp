@@ -12,6 +12,9 @@
 //   loadToCpu / loadToCuda / save     same file format         (tensor.cuh:126-163)
 //   view (aliases storage)            same                     (tensor.cuh:165-170)
 //   toDevice / cuda / cpu             rn_memcpy_h2d / d2h      (tensor.cuh:184-209)
+//   data()                            same pointer; on a GPU tensor it first runs what the layer
+//                                     classes recorded and gives the buffer its NCHW content back
+//                                     (rn_observe): forward() calls are deferred, see rn_hip.h
 //   gpuAssert(code, file, line, abort) same: message on stderr, then abort
 //                                                              (helpers.cuh:13-22)
 //   safeCudaMalloc(size)              rn_malloc, checked; -DDEBUG logs every allocation
@@ -64,6 +67,11 @@ inline rn_ctx *context()
         }
         rn_ctx_set_sync_each_op(c, 1);  // the reference synchronises after every op
         rn_ctx_set_weight_cache(c, 1);  // layers own their weights (nn.cuh:13): pack each once
+        // forward() calls are recorded and run when a result is observed (cpu(), data(), a free), with
+        // conv + in-place batch-norm / add / ReLU as one fused launch (rn_ctx_set_deferred, rn_hip.h);
+        // RN_VENEER_LITERAL=1 in the environment: one launch per call, at once, as the reference does
+        const char *literal = std::getenv("RN_VENEER_LITERAL");
+        rn_ctx_set_deferred(c, (literal && literal[0] == '1') ? 0 : 1);
         return c;
     }();
     return ctx;
@@ -221,9 +229,9 @@ struct Tensor {
         Tensor ret(shape_, to);
         ret.layout = layout;
         if (device == Device::CPU && to == Device::GPU) {
-            gpuErrchk(rn_memcpy_h2d(rn::context(), ret.data(), data(), size()));
+            gpuErrchk(rn_memcpy_h2d(rn::context(), ret.raw(), raw(), size()));
         } else if (device == Device::GPU && to == Device::CPU) {
-            gpuErrchk(rn_memcpy_d2h(rn::context(), ret.data(), data(), size()));
+            gpuErrchk(rn_memcpy_d2h(rn::context(), ret.raw(), raw(), size()));
         } else {
             throw std::runtime_error("Unsupported device transfer combination");
         }
@@ -234,7 +242,14 @@ struct Tensor {
 
     explicit operator bool() const { return static_cast<bool>(storage_); }
     const Shape &shape() const { return shape_; }
-    T *data() const { return storage_.get(); }
+    // the pointer for the caller's own use: what was recorded runs and the buffer holds its NCHW content
+    // (rn_observe); the layer classes hand raw() to the library, which knows what each buffer holds
+    T *data() const
+    {
+        if (device == Device::GPU && storage_) gpuErrchk(rn_observe(rn::context(), storage_.get()));
+        return storage_.get();
+    }
+    T *raw() const { return storage_.get(); }
 
     const Device device;
     Layout layout = Layout::NCHW;

@@ -95,6 +95,40 @@ RN_API int rn_ctx_set_layout(rn_ctx *ctx, int layout);
 RN_API int rn_ctx_get_layout(const rn_ctx *ctx);
 /* 1: synchronise and check after every op, like the reference (nn.cu:14-15). Default 0. */
 RN_API int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on);
+/* Deferred execution of the reference's op-by-op call sequence (main.cu:127-166: conv.forward,
+ * bn.forward in place, [addForward in place], reluForward in place -- separate launches, each a pass
+ * over its tensor).  on = 1: with the context in its NCHW layout the seven reference entry points
+ * (rn_conv2d_forward, rn_batchnorm2d_forward, rn_relu_forward, rn_add_forward, rn_maxpool2d_forward,
+ * rn_avgpool2d_forward, rn_linear_forward) only RECORD their call and return.  The recorded list runs
+ * when something is observed -- rn_memcpy_d2h / rn_save_f32_file, rn_sync, rn_flush, rn_observe,
+ * rn_event_record, rn_free, a write into a buffer it names, or any other entry point -- and then a
+ * convolution with the in-place batch-norm / add / ReLU that follow it on its output buffer is ONE
+ * launch of the NHWC contraction with the fused epilogue (folded batch-norm, residual, ReLU), which
+ * writes NHWC into the caller's own output buffer.  The context remembers which caller buffers hold
+ * NHWC: ops that follow run on them as NHWC (no transposes between the first and the last op of a
+ * network), and a buffer gets its NCHW content back only when it is observed (a whole-tensor
+ * rn_memcpy_d2h transposes on its way out; rn_observe, partial reads, device-to-device copies and
+ * entry points outside the seven rewrite the buffer in place first).  Every buffer named as an output
+ * holds its value once the list has run: only in-place chains are folded, nothing is skipped.
+ * Contract for the caller: device memory it handed to the seven ops is read and written by other
+ * means (own kernels, hipMemcpy) only after rn_observe(ctx, ptr) -- the C++ veneer's Tensor::data()
+ * does that; weights and batch-norm parameters are cached in packed / folded form per buffer and the
+ * cache follows writes made through rn_* calls only (like rn_ctx_set_weight_cache).
+ * Numerics: the folded batch-norm is one fp32 fmaf per element instead of ops.cu:150's double
+ * expression (<= 2e-5 on ResNet logits; the same epilogue as RN_FWD_FUSED).  on = 0 (default): every
+ * call launches at once on NCHW tensors, the parity baseline; switching off runs what is recorded and
+ * gives every buffer its NCHW content back. */
+RN_API int rn_ctx_set_deferred(rn_ctx *ctx, int on);
+RN_API int rn_ctx_get_deferred(const rn_ctx *ctx);
+/* run the recorded ops now (asynchronously, on the context's stream) */
+RN_API int rn_flush(rn_ctx *ctx);
+/* run the recorded ops and make the caller buffer at dev_ptr hold its NCHW content */
+RN_API int rn_observe(rn_ctx *ctx, const void *dev_ptr);
+/* counters of the deferred route: ops recorded and not yet run, caller buffers currently NHWC, launches
+ * with a folded chain, literal launches, layout passes (transposes) so far; any pointer may be NULL */
+RN_API int rn_ctx_deferred_stats(const rn_ctx *ctx, uint64_t *pending_ops, uint64_t *nhwc_buffers,
+                                 uint64_t *fused_launches, uint64_t *literal_launches,
+                                 uint64_t *transposes);
 /* Tile shape of the contraction kernel: 0 = chosen per launch (default), 1..N = force
  * candidate i (all candidates give bit-identical results; used by rn_model_tune). */
 /* rn_conv2d_forward (the reference's OIHW / NCHW signature) re-packs the weight into the

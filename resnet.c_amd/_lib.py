@@ -41,6 +41,11 @@ SIGNATURES = {
     "rn_ctx_set_layout": (c_int, [c_void_p, c_int]),
     "rn_ctx_get_layout": (c_int, [c_void_p]),
     "rn_ctx_set_sync_each_op": (c_int, [c_void_p, c_int]),
+    "rn_ctx_set_deferred": (c_int, [c_void_p, c_int]),
+    "rn_ctx_get_deferred": (c_int, [c_void_p]),
+    "rn_flush": (c_int, [c_void_p]),
+    "rn_observe": (c_int, [c_void_p, c_void_p]),
+    "rn_ctx_deferred_stats": (c_int, [c_void_p] + [POINTER(u64)] * 5),
     "rn_ctx_set_weight_cache": (c_int, [c_void_p, c_int]),
     "rn_ctx_launch_count": (u64, [c_void_p]),
     "rn_conv_tile_candidates": (c_int, []),

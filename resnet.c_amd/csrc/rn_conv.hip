@@ -1257,11 +1257,15 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
                       uint64_t w_out, uint64_t B, uint64_t in_channels, uint64_t out_channels,
                       uint64_t H, uint64_t W)
 {
-    RN_ENTER(ctx);
+    if (!ctx) return RN_ERR_INVALID;
     if (B * out_channels * h_out * w_out == 0) return RN_OK;
     RN_TRY(check_conv_args(ctx, inp, out, weight, kernel_size, stride, padding, h_out, w_out, B,
                            in_channels, out_channels, H, W));
     RN_REQUIRE(ctx, in_channels >= 1, "in_channels must be >= 1");
+    if (RN_DEFERS(ctx))  // recorded; runs with the in-place batch-norm / add / ReLU behind it folded in (rn_defer.hip)
+        return rn_defer_conv(ctx, inp, out, weight, kernel_size, stride, padding, h_out, w_out, B, in_channels,
+                             out_channels, H, W);
+    RN_ENTER(ctx);
     const bool c4 = rn_conv_is_c4(in_channels, kernel_size);
     const bool fast = (in_channels % 32 == 0 || c4) && kernel_size <= 15 &&
                       B * H * W * rn_conv2d_input_channels(in_channels) < (1ull << 29) &&
@@ -1442,7 +1446,7 @@ int rn_conv2d_nhwc_pair_forward_dt(rn_ctx *ctx, int dtype, int out_dtype, const 
 int rn_linear_forward(rn_ctx *ctx, const float *inp, float *out, const float *weight,
                       const float *bias, uint64_t B, uint64_t in_features, uint64_t out_features)
 {
-    RN_ENTER(ctx);
+    if (!ctx) return RN_ERR_INVALID;
     if (B * out_features == 0) return RN_OK;
     RN_REQUIRE(ctx, inp && out && weight, "null tensor");
     RN_REQUIRE(ctx, inp != out, "linear cannot run in place");
@@ -1450,6 +1454,8 @@ int rn_linear_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
     RN_REQUIRE(ctx, fits_i32(B * in_features) && fits_i32(B * out_features) &&
                         fits_i32(out_features * in_features + 64),
                "tensor has 2^31 or more elements");
+    if (RN_DEFERS(ctx)) return rn_defer_linear(ctx, inp, out, weight, bias, B, in_features, out_features);
+    RN_ENTER(ctx);
     rn_epilogue ep = {nullptr, bias, nullptr, 0};
     // W is [out][in] row-major == the K-major panel of a 1x1 convolution on a 1x1 image
     if (in_features % 32 == 0 &&

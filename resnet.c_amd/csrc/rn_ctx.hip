@@ -223,7 +223,9 @@ int rn_ctx_destroy(rn_ctx *ctx)
 {
     if (!ctx) return RN_OK;
     (void)hipSetDevice(ctx->device);
+    (void)rn_defer_flush(ctx);  // recorded ops run (their outputs may be read through other contexts later)
     (void)hipStreamSynchronize(ctx->stream);
+    rn_defer_destroy(ctx);
     for (int i = 0; i < 5; ++i) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     }
@@ -239,6 +241,12 @@ int rn_ctx_set_layout(rn_ctx *ctx, int layout)
     if (!ctx) return RN_ERR_INVALID;
     if (layout != RN_LAYOUT_NCHW && layout != RN_LAYOUT_NHWC)
         return rn_set_error(ctx, RN_ERR_INVALID, "unknown layout %d", layout);
+    if (ctx->ds && !ctx->defer_running && layout != ctx->layout) {
+        // recorded ops were called under the old layout; buffers tagged NHWC by the deferred route
+        // get their NCHW content back before the caller starts to say what layout tensors have
+        RN_TRY(rn_bind_device(ctx));
+        RN_TRY(rn_defer_barrier(ctx));
+    }
     ctx->layout = layout;
     return RN_OK;
 }
@@ -319,6 +327,7 @@ int rn_sync(rn_ctx *ctx)
 {
     if (!ctx) return RN_ERR_INVALID;
     RN_TRY(rn_bind_device(ctx));
+    RN_TRY(rn_defer_flush(ctx));  // "everything I called has run" includes the recorded ops
     RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     RN_HIP_TRY(ctx, hipGetLastError());
     return RN_OK;
@@ -346,6 +355,16 @@ int rn_free(rn_ctx *ctx, void *dev_ptr)
     if (!ctx) return RN_ERR_INVALID;
     RN_TRY(rn_bind_device(ctx));
     if (!dev_ptr) return RN_OK;
+    if (ctx->ds) {  // recorded ops may name this buffer: they run first; its tag and folded constants go
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, dev_ptr) == hipSuccess) {
+            RN_TRY(rn_defer_before_write(ctx, base, size, 1));
+        } else {
+            (void)hipGetLastError();
+            RN_TRY(rn_defer_before_write(ctx, dev_ptr, 1, 1));
+        }
+    }
     RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->wcache_n) {  // panels packed from weights inside this allocation are stale now
         hipDeviceptr_t base = nullptr;
@@ -364,6 +383,7 @@ int rn_memcpy_h2d(rn_ctx *ctx, void *dev_dst, const void *host_src, uint64_t byt
     if (!ctx || (bytes && (!dev_dst || !host_src))) return RN_ERR_INVALID;
     RN_TRY(rn_bind_device(ctx));
     if (!bytes) return RN_OK;
+    if (ctx->ds) RN_TRY(rn_defer_before_write(ctx, dev_dst, bytes, 0));
     if (ctx->wcache_n) rn_wcache_drop(ctx, dev_dst, bytes);
     RN_HIP_TRY(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -375,6 +395,9 @@ int rn_memcpy_d2h(rn_ctx *ctx, void *host_dst, const void *dev_src, uint64_t byt
     if (!ctx || (bytes && (!host_dst || !dev_src))) return RN_ERR_INVALID;
     RN_TRY(rn_bind_device(ctx));
     if (!bytes) return RN_OK;
+    // a buffer the deferred route holds as NHWC goes out as NCHW: a whole tensor through scratch (the
+    // buffer stays NHWC for the ops that follow), anything else after an in-place rewrite
+    if (ctx->ds) RN_TRY(rn_defer_before_read(ctx, dev_src, bytes, &dev_src));
     RN_HIP_TRY(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     RN_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RN_OK;
@@ -385,6 +408,10 @@ int rn_memcpy_d2d(rn_ctx *ctx, void *dev_dst, const void *dev_src, uint64_t byte
     if (!ctx || (bytes && (!dev_dst || !dev_src))) return RN_ERR_INVALID;
     RN_TRY(rn_bind_device(ctx));
     if (!bytes) return RN_OK;
+    if (ctx->ds) {
+        RN_TRY(rn_defer_before_read(ctx, dev_src, bytes, nullptr));
+        RN_TRY(rn_defer_before_write(ctx, dev_dst, bytes, 0));
+    }
     if (ctx->wcache_n) rn_wcache_drop(ctx, dev_dst, bytes);
     RN_HIP_TRY(ctx,
                hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -396,6 +423,7 @@ int rn_memset(rn_ctx *ctx, void *dev_ptr, int byte_value, uint64_t bytes)
     if (!ctx || (bytes && !dev_ptr)) return RN_ERR_INVALID;
     RN_TRY(rn_bind_device(ctx));
     if (!bytes) return RN_OK;
+    if (ctx->ds) RN_TRY(rn_defer_before_write(ctx, dev_ptr, bytes, 0));
     if (ctx->wcache_n) rn_wcache_drop(ctx, dev_ptr, bytes);
     RN_HIP_TRY(ctx, hipMemsetAsync(dev_ptr, byte_value, bytes, ctx->stream));
     return RN_OK;
@@ -490,6 +518,7 @@ int rn_event_record(rn_ctx *ctx, rn_event *ev)
 {
     if (!ctx || !ev) return RN_ERR_INVALID;
     RN_TRY(rn_bind_device(ctx));
+    RN_TRY(rn_defer_flush(ctx));  // an event marks "after everything called so far": recorded ops included
     RN_HIP_TRY(ctx, hipEventRecord(ev->ev, ctx->stream));
     return RN_OK;
 }

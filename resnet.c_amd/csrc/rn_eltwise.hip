@@ -317,9 +317,11 @@ extern "C" {
 
 int rn_relu_forward(rn_ctx *ctx, const float *inp, float *out, uint64_t N)
 {
-    RN_ENTER(ctx);
+    if (!ctx) return RN_ERR_INVALID;
     RN_REQUIRE(ctx, N == 0 || (inp && out), "null tensor");
     if (N == 0) return RN_OK;
+    if (RN_DEFERS(ctx)) return rn_defer_eltwise(ctx, 0, inp, nullptr, out, N);
+    RN_ENTER(ctx);
     if (aligned16(inp) && aligned16(out)) {
         const uint64_t n4 = N / 4;
         relu_kernel<<<rn_stream_grid(n4, kBlock), kBlock, 0, ctx->stream>>>(inp, out, n4, N);
@@ -331,9 +333,11 @@ int rn_relu_forward(rn_ctx *ctx, const float *inp, float *out, uint64_t N)
 
 int rn_add_forward(rn_ctx *ctx, const float *inp1, const float *inp2, float *out, uint64_t N)
 {
-    RN_ENTER(ctx);
+    if (!ctx) return RN_ERR_INVALID;
     RN_REQUIRE(ctx, N == 0 || (inp1 && inp2 && out), "null tensor");
     if (N == 0) return RN_OK;
+    if (RN_DEFERS(ctx)) return rn_defer_eltwise(ctx, 1, inp1, inp2, out, N);
+    RN_ENTER(ctx);
     if (aligned16(inp1) && aligned16(inp2) && aligned16(out)) {
         const uint64_t n4 = N / 4;
         add_kernel<<<rn_stream_grid(n4, kBlock), kBlock, 0, ctx->stream>>>(inp1, inp2, out, n4,
@@ -349,11 +353,13 @@ int rn_batchnorm2d_forward(rn_ctx *ctx, const float *inp, float *out, const floa
                            const float *bias, const float *mean, const float *var, uint64_t B,
                            uint64_t C, uint64_t N)
 {
-    RN_ENTER(ctx);
+    if (!ctx) return RN_ERR_INVALID;
     const uint64_t total = B * C * N;
     if (total == 0) return RN_OK;
     RN_REQUIRE(ctx, inp && out && weight && bias && mean && var, "null tensor");
     RN_REQUIRE(ctx, C < (1ull << 31) && N < (1ull << 32), "dimension too large");
+    if (RN_DEFERS(ctx)) return rn_defer_bn(ctx, inp, out, weight, bias, mean, var, B, C, N);
+    RN_ENTER(ctx);
     void *scratch = nullptr;
     RN_TRY(rn_scratch(ctx, 0, C * kBnStride * sizeof(double), &scratch));
     double *params = static_cast<double *>(scratch);

@@ -38,6 +38,11 @@ struct rn_ctx {
     // shape -> K-major panel, packed on first use; off unless rn_ctx_set_weight_cache(ctx, 1)
     int wcache_on, wcache_n, wcache_cap;
     struct rn_wcache_entry *wcache;
+    // deferred execution of the reference's op-by-op calls (rn_defer.hip): recorded ops, the caller
+    // buffers that currently hold NHWC, folded batch-norm constants
+    int defer;          // rn_ctx_set_deferred
+    int defer_running;  // the recorded list (or a layout rewrite) is executing: entry points run for real
+    struct rn_defer_state *ds;
     char err[512];
 };
 
@@ -70,11 +75,37 @@ int rn_after_launch(rn_ctx *ctx, const char *what);
         if (rn_st_ != RN_OK) return rn_st_;                    \
     } while (0)
 
+// rn_defer.hip.  flush: run the recorded ops; barrier: flush + every caller buffer back to NCHW;
+// before_write / before_read: an access to caller memory from outside the recorded list
+int rn_defer_flush(rn_ctx *ctx);
+int rn_defer_barrier(rn_ctx *ctx);
+int rn_defer_before_write(rn_ctx *ctx, const void *ptr, uint64_t bytes, int whole_allocation);
+int rn_defer_before_read(rn_ctx *ctx, const void *ptr, uint64_t bytes, const void **alt);
+void rn_defer_destroy(rn_ctx *ctx);
+int rn_defer_conv(rn_ctx *ctx, const float *inp, float *out, const float *w, uint64_t k, uint64_t s, uint64_t p,
+                  uint64_t ho, uint64_t wo, uint64_t B, uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W);
+int rn_defer_bn(rn_ctx *ctx, const float *inp, float *out, const float *w, const float *b, const float *mean,
+                const float *var, uint64_t B, uint64_t C, uint64_t N);
+int rn_defer_eltwise(rn_ctx *ctx, int is_add, const float *a, const float *b, float *out, uint64_t N);
+int rn_defer_pool(rn_ctx *ctx, int is_max, const float *inp, float *out, uint64_t k, uint64_t s, uint64_t p,
+                  uint64_t ho, uint64_t wo, uint64_t B, uint64_t C, uint64_t H, uint64_t W);
+int rn_defer_linear(rn_ctx *ctx, const float *inp, float *out, const float *w, const float *b, uint64_t B,
+                    uint64_t in_f, uint64_t out_f);
+// a reference entry point on a deferred context in its NCHW layout records its call instead of launching
+#define RN_DEFERS(ctx) ((ctx)->defer && !(ctx)->defer_running && (ctx)->layout == RN_LAYOUT_NCHW)
+
+// every entry point that touches the device: bind the device; on a context with deferred state, run what
+// has been recorded and give every caller buffer its NCHW content back first (the seven reference ops
+// record themselves before they get here; the copies and frees of rn_ctx.hip have finer rules)
 #define RN_ENTER(ctx)                                  \
     do {                                               \
         if (!(ctx)) return RN_ERR_INVALID;             \
         int rn_en_ = rn_bind_device(ctx);              \
         if (rn_en_ != RN_OK) return rn_en_;            \
+        if ((ctx)->ds && !(ctx)->defer_running) {      \
+            rn_en_ = rn_defer_barrier(ctx);            \
+            if (rn_en_ != RN_OK) return rn_en_;        \
+        }                                              \
     } while (0)
 
 #define RN_TRY(expr)                       \

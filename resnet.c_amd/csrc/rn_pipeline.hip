@@ -2,8 +2,13 @@
 // runs the forward and downloads the logits strictly in sequence with a device
 // synchronisation between every step (main.cu:236-240, tensor.cuh:184-199); at 13k images/s a
 // 154 MB batch upload (2.4 ms on PCIe Gen5 x16) would cost 13 % if it were not overlapped.
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
+
+#include <atomic>
+#include <thread>
+#include <vector>
 
 #include "rn_internal.h"
 
@@ -32,6 +37,7 @@ struct rn_pipeline {
     uint64_t B;
     int mode;
     hipStream_t copy_stream;
+    int copy_threads;  // helper threads of the pageable -> pinned copy (RN_COPY_THREADS, default 3)
     rn_pipeline_slot slot[2];
     uint64_t head, tail;  // submitted / collected counts
 };
@@ -154,6 +160,11 @@ int rn_pipeline_create(rn_model *m, rn_pipeline **out, uint64_t B, int mode)
     p->ctx = ctx;
     p->B = B;
     p->mode = mode;
+    {
+        const char *ct = getenv("RN_COPY_THREADS");
+        const int n = ct ? atoi(ct) : 3;
+        p->copy_threads = n < 1 ? 1 : n > 16 ? 16 : n;
+    }
     const size_t in_bytes = (size_t)B * 3 * 224 * 224 * sizeof(float);
     const size_t out_bytes = (size_t)B * 1000 * sizeof(float);
     const size_t idx_bytes = (size_t)B * sizeof(uint64_t);
@@ -206,14 +217,45 @@ int rn_pipeline_submit_n(rn_pipeline *p, const float *host_input_nchw, uint64_t 
     const int st = [&]() -> int {
         if (host_input_nchw && host_input_nchw != s->h_in) {
             // pageable -> pinned -> device in pieces of 16 images (9.6 MB): the upload of piece i runs on the
-            // copy stream while this thread copies piece i+1, so a batch costs max(copy, upload) instead of
-            // their sum before its forward can start (a 154 MB fp32 batch: ~4 ms each)
+            // copy stream while piece i+1 is being copied, so a batch costs max(copy, upload) instead of their
+            // sum before its forward can start.  One core copies a 154 MB fp32 batch in 6-7 ms (23 GB/s), which
+            // is longer than its upload (3.8 ms) and than a bf16 forward (3.3 ms): the pieces are copied by
+            // `copiers` helper threads (they inherit this thread's CPU affinity: the cores local to the device)
+            // while this thread queues each piece's upload as soon as it has landed in staging.
             const size_t piece = (size_t)16 * 3 * 224 * 224 * sizeof(float);
-            for (size_t at = 0; at < in_bytes; at += piece) {
-                const size_t nb = in_bytes - at < piece ? in_bytes - at : piece;
+            const size_t npieces = (in_bytes + piece - 1) / piece;
+            const int copiers = npieces >= 4 ? p->copy_threads : 1;
+            auto copy_piece = [&](size_t i) {
+                const size_t at = i * piece, nb = in_bytes - at < piece ? in_bytes - at : piece;
                 memcpy((char *)s->h_in + at, (const char *)host_input_nchw + at, nb);
-                RN_HIP_TRY(ctx, hipMemcpyAsync((char *)s->d_in + at, (char *)s->h_in + at, nb, hipMemcpyHostToDevice,
-                                               p->copy_stream));
+            };
+            auto upload_piece = [&](size_t i) -> hipError_t {
+                const size_t at = i * piece, nb = in_bytes - at < piece ? in_bytes - at : piece;
+                return hipMemcpyAsync((char *)s->d_in + at, (char *)s->h_in + at, nb, hipMemcpyHostToDevice, p->copy_stream);
+            };
+            if (copiers <= 1) {
+                for (size_t i = 0; i < npieces; ++i) {
+                    copy_piece(i);
+                    RN_HIP_TRY(ctx, upload_piece(i));
+                }
+            } else {
+                std::vector<std::atomic<int>> landed(npieces);
+                for (auto &f : landed) f.store(0, std::memory_order_relaxed);
+                std::vector<std::thread> pool;
+                for (int t = 0; t < copiers; ++t)
+                    pool.emplace_back([&, t]() {
+                        for (size_t i = (size_t)t; i < npieces; i += (size_t)copiers) {
+                            copy_piece(i);
+                            landed[i].store(1, std::memory_order_release);
+                        }
+                    });
+                hipError_t e = hipSuccess;
+                for (size_t i = 0; i < npieces && e == hipSuccess; ++i) {
+                    while (!landed[i].load(std::memory_order_acquire)) sched_yield();
+                    e = upload_piece(i);
+                }
+                for (auto &th : pool) th.join();  // also on an error: the threads write into the slot's staging
+                RN_HIP_TRY(ctx, e);
             }
         } else {
             RN_HIP_TRY(ctx, hipMemcpyAsync(s->d_in, s->h_in, in_bytes, hipMemcpyHostToDevice, p->copy_stream));

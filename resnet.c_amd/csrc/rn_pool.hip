@@ -435,7 +435,7 @@ int pool_dispatch(rn_ctx *ctx, const float *inp, float *out, uint64_t k, uint64_
                   uint64_t pad, uint64_t h_out, uint64_t w_out, uint64_t B, uint64_t C, uint64_t H,
                   uint64_t W, const char *what)
 {
-    RN_ENTER(ctx);
+    if (!ctx) return RN_ERR_INVALID;
     const uint64_t total = B * C * h_out * w_out;
     if (total == 0) return RN_OK;
     RN_REQUIRE(ctx, inp && out, "null tensor");
@@ -445,6 +445,8 @@ int pool_dispatch(rn_ctx *ctx, const float *inp, float *out, uint64_t k, uint64_
                         pad < (1u << 15) && stride < (1u << 15),
                "dimension too large");
     RN_REQUIRE(ctx, h_out < (1u << 30) && w_out < (1u << 30), "dimension too large");
+    if (RN_DEFERS(ctx)) return rn_defer_pool(ctx, kMax ? 1 : 0, inp, out, k, stride, pad, h_out, w_out, B, C, H, W);
+    RN_ENTER(ctx);
     const bool al = ((reinterpret_cast<uintptr_t>(inp) | reinterpret_cast<uintptr_t>(out)) & 15) ==
                     0;
     if (ctx->layout == RN_LAYOUT_NHWC && al && C % 4 == 0 && total / 4 < (1ull << 32)) {

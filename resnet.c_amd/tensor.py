@@ -67,6 +67,24 @@ class Context:
     def set_sync_each_op(self, on: bool) -> None:
         L.check(L.lib().rn_ctx_set_sync_each_op(self.handle, int(on)), "rn_ctx_set_sync_each_op")
 
+    def set_deferred(self, on: bool) -> None:
+        """rn_ctx_set_deferred: the seven reference ops record their calls; the list runs when something is
+        observed, with conv + in-place batch-norm / add / ReLU as one fused NHWC launch (rn_hip.h)."""
+        L.check(L.lib().rn_ctx_set_deferred(self.handle, int(on)), "rn_ctx_set_deferred", self.handle)
+
+    def flush(self) -> None:
+        L.check(L.lib().rn_flush(self.handle), "rn_flush", self.handle)
+
+    def observe(self, dev_ptr) -> None:
+        L.check(L.lib().rn_observe(self.handle, dev_ptr), "rn_observe", self.handle)
+
+    def deferred_stats(self) -> dict:
+        import ctypes
+        v = [ctypes.c_uint64() for _ in range(5)]
+        L.check(L.lib().rn_ctx_deferred_stats(self.handle, *(ctypes.byref(x) for x in v)), "rn_ctx_deferred_stats")
+        return dict(zip(("pending_ops", "nhwc_buffers", "fused_launches", "literal_launches", "transposes"),
+                        (int(x.value) for x in v)))
+
     def set_weight_cache(self, on: bool) -> None:
         """rn_conv2d_forward (OIHW weights) packs each weight buffer once instead of per call."""
         L.check(L.lib().rn_ctx_set_weight_cache(self.handle, int(on)), "rn_ctx_set_weight_cache")

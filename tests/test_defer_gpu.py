@@ -1,0 +1,284 @@
+"""Deferred execution of the reference's op-by-op call sequence (rn_ctx_set_deferred, rn_defer.hip):
+the seven reference entry points record their calls, a convolution runs together with the in-place
+batch-norm / add / ReLU behind it as ONE fused NHWC launch into the caller's own buffer, and a buffer
+gets its NCHW content back when it is observed.  Held against the literal route (one launch per call,
+the parity baseline), the oracle and the reference module's golden logits."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import resnet_c_amd as R
+from oracle import oracle as O
+from resnet_c_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rnd(shape, seed, scale=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape, dtype=np.float32) * scale).astype(np.float32)
+
+
+@pytest.fixture()
+def dctx():
+    ctx = R.get_ctx()
+    ctx.set_deferred(True)
+    yield ctx
+    ctx.set_deferred(False)
+    assert ctx.deferred_stats()["pending_ops"] == 0 and ctx.deferred_stats()["nhwc_buffers"] == 0
+
+
+def gpu(a):
+    return R.FloatTensor.from_numpy(np.ascontiguousarray(a, dtype=np.float32), R.Device.GPU)
+
+
+def bn_params(C, seed):
+    g = np.random.default_rng(seed)
+    return (g.random(C, dtype=np.float32) + 0.5, g.standard_normal(C, dtype=np.float32) * 0.1,
+            g.standard_normal(C, dtype=np.float32) * 0.1, g.random(C, dtype=np.float32) + 0.5)
+
+
+def call(ctx, name, *args):
+    L.check(getattr(L.lib(), name)(ctx.handle, *args), name, ctx.handle)
+
+
+def test_whole_network_deferred_matches_goldens_and_the_literal_route(state50, finch, golden_dir, dctx):
+    """createResnet / resnetForward (the reference driver object for object, one C-ABI call per reference
+    op on NCHW tensors) on a deferred context: 53 fused launches, no literal batch-norm / ReLU / add pass,
+    one layout pass for the input; logits within the bar of the reference module's goldens and within the
+    fused epilogue's distance of the literal route; intermediate tensors come back as NCHW when observed."""
+    x = np.concatenate([finch, R.weights.generate_input(2, seed=5)])
+    dctx.set_deferred(False)
+    m = R.createResnet("resnet50", state50)
+    xd = gpu(x)
+    literal = R.resnetForward(m, xd).numpy().copy()
+    lit_l1 = m.layer1.blocks[0].act3_out.numpy().copy()
+    lit_t = m.layer3.blocks[2].act2_out.numpy().copy()
+    dctx.set_deferred(True)
+    s0 = dctx.deferred_stats()
+    out = R.resnetForward(m, xd)
+    assert dctx.deferred_stats()["pending_ops"] == 174          # nothing has run yet (main.cu: 174 ops)
+    got = out.numpy()                                           # observed: the list runs
+    s1 = dctx.deferred_stats()
+    assert s1["pending_ops"] == 0
+    assert s1["fused_launches"] - s0["fused_launches"] == 53    # every convolution with its chain folded in
+    assert s1["literal_launches"] - s0["literal_launches"] == 3  # max-pool, avg-pool, fc
+    assert s1["transposes"] - s0["transposes"] == 1             # the NCHW input image -> padded NHWC
+    want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
+    assert np.abs(got[:1] - want).max() <= 1e-4
+    assert np.abs(got - literal).max() <= 5e-5
+    assert np.array_equal(got.argmax(1), literal.argmax(1)) and int(got[0].argmax()) == 112
+    # tensors inside the network are NHWC in their buffers now; read, they are the literal route's NCHW values
+    a = m.layer1.blocks[0].act3_out.numpy()
+    assert np.abs(a - lit_l1).max() <= 2e-5 * max(1.0, float(np.abs(lit_l1).max()))
+    t = m.layer3.blocks[2].act2_out.numpy()
+    assert np.abs(t - lit_t).max() <= 2e-5 * max(1.0, float(np.abs(lit_t).max()))
+    assert dctx.deferred_stats()["nhwc_buffers"] > 40           # whole-tensor reads leave the buffers NHWC
+    again = R.resnetForward(m, xd).numpy()                      # and the next forward runs on them as before
+    assert np.array_equal(again, got)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 14, 14, 3, 1, 1), (3, 32, 96, 9, 7, 1, 1, 0), (2, 64, 128, 12, 12, 1, 2, 0),
+                                  (1, 128, 32, 7, 7, 3, 2, 1), (2, 3, 64, 32, 32, 7, 2, 3)])
+def test_fused_chain_against_the_oracle(case, dctx):
+    """conv -> bn (in place) -> add (in place) -> relu (in place) recorded, run as one launch: against the
+    oracle's four ops; the residual once as a plain NCHW tensor (transposed on the way in) and once as the
+    NHWC output of an earlier deferred convolution."""
+    B, Cin, Cout, H, W, k, s, p = case
+    seed = sum(case)
+    x, w = rnd((B, Cin, H, W), seed), rnd((Cout, Cin, k, k), seed + 1, 1.0 / np.sqrt(Cin * k * k))
+    bw, bb, bm, bv = bn_params(Cout, seed + 2)
+    ho, wo = O.conv_output_size(H, k, s, p), O.conv_output_size(W, k, s, p)
+    res = rnd((B, Cout, ho, wo), seed + 3)
+    want = O.relu_(O.add_(O.batchnorm2d_(O.conv2d(x, w, s, p), bw, bb, bm, bv), res))
+    dx, dw, dres = gpu(x), gpu(w), gpu(res)
+    P = [gpu(v) for v in (bw, bb, bm, bv)]
+    out = R.FloatTensor((B, Cout, ho, wo), R.Device.GPU)
+    n = B * Cout * ho * wo
+
+    def chain(residual):
+        call(dctx, "rn_conv2d_forward", dx.data(), out.data(), dw.data(), k, s, p, ho, wo, B, Cin, Cout, H, W)
+        call(dctx, "rn_batchnorm2d_forward", out.data(), out.data(), *(t.data() for t in P), B, Cout, ho * wo)
+        call(dctx, "rn_add_forward", out.data(), residual.data(), out.data(), n)
+        call(dctx, "rn_relu_forward", out.data(), out.data(), n)
+
+    s0 = dctx.deferred_stats()
+    chain(dres)
+    got = out.numpy()
+    s1 = dctx.deferred_stats()
+    assert s1["fused_launches"] - s0["fused_launches"] == 1 and s1["literal_launches"] == s0["literal_launches"]
+    tol = 3e-6 * np.sqrt(Cin * k * k) * float(np.abs(want).max()) + 1e-5
+    assert np.abs(got - want).max() <= tol
+    # the residual produced by a deferred 1x1 convolution of the same shape: NHWC-tagged, used in place
+    w2 = rnd((Cout, Cout, 1, 1), seed + 4, 1.0 / np.sqrt(Cout))
+    r2 = R.FloatTensor((B, Cout, ho, wo), R.Device.GPU)
+    dw2 = gpu(w2)
+    if Cout % 32 == 0:
+        call(dctx, "rn_conv2d_forward", dres.data(), r2.data(), dw2.data(), 1, 1, 0, ho, wo, B, Cout, Cout, ho, wo)
+        t0 = dctx.deferred_stats()["transposes"]
+        chain(r2)
+        got2 = out.numpy()
+        res2 = O.conv2d(res, w2, 1, 0)
+        want2 = O.relu_(O.add_(O.batchnorm2d_(O.conv2d(x, w, s, p), bw, bb, bm, bv), res2))
+        assert np.abs(got2 - want2).max() <= tol + 3e-6 * np.sqrt(Cout) * float(np.abs(res2).max())
+        # layout passes: dres -> NHWC for the 1x1, x -> NHWC for the chain, out -> NCHW for the read; none for r2
+        assert dctx.deferred_stats()["transposes"] - t0 == (3 if H * W > 1 else 1)
+
+
+def test_sequences_that_do_not_fold_run_literally_in_call_order(dctx):
+    """Only conv -> [bn] -> [add] -> [relu], each in place on the convolution's output, folds.  Another
+    order, another buffer, a shape without an NHWC contraction: literal launches in call order, same
+    values as the literal route bit for bit (they ARE the literal kernels; on NHWC-tagged inputs the NHWC
+    forms of batch-norm / ReLU / add / pools, which are bit-identical to the NCHW forms)."""
+    B, C, H, W = 2, 32, 10, 10
+    x, w = rnd((B, C, H, W), 1), rnd((C, C, 3, 3), 2, 0.06)
+    bw, bb, bm, bv = bn_params(C, 3)
+    other = rnd((B, C, H, W), 4)
+    w5 = rnd((8, 5, 3, 3), 5, 0.2)
+    x5 = rnd((B, 5, H, W), 6)
+
+    def program(ctx):
+        dx, dw, dother, dw5, dx5 = gpu(x), gpu(w), gpu(other), gpu(w5), gpu(x5)
+        P = [gpu(v) for v in (bw, bb, bm, bv)]
+        t = R.FloatTensor((B, C, H, W), R.Device.GPU)
+        u = R.FloatTensor((B, C, H, W), R.Device.GPU)
+        v = R.FloatTensor((B, 8, H, W), R.Device.GPU)
+        pool = R.FloatTensor((B, C, 5, 5), R.Device.GPU)
+        n = B * C * H * W
+        call(ctx, "rn_conv2d_forward", dx.data(), t.data(), dw.data(), 3, 1, 1, H, W, B, C, C, H, W)
+        call(ctx, "rn_relu_forward", t.data(), t.data(), n)                       # relu BEFORE bn: relu folds, bn does not
+        call(ctx, "rn_batchnorm2d_forward", t.data(), t.data(), *(q.data() for q in P), B, C, H * W)
+        call(ctx, "rn_batchnorm2d_forward", t.data(), u.data(), *(q.data() for q in P), B, C, H * W)   # out of place
+        call(ctx, "rn_add_forward", u.data(), dother.data(), u.data(), n)         # NHWC-tagged + plain NCHW operand
+        call(ctx, "rn_maxpool2d_forward", t.data(), pool.data(), 3, 2, 1, 5, 5, B, C, H, W)
+        call(ctx, "rn_conv2d_forward", dx5.data(), v.data(), dw5.data(), 3, 1, 1, H, W, B, 5, 8, H, W)  # Cin = 5: direct kernel
+        call(ctx, "rn_relu_forward", v.data(), v.data(), B * 8 * H * W)
+        return [a.numpy() for a in (t, u, pool, v)]
+
+    dctx.set_deferred(False)
+    want = program(dctx)
+    dctx.set_deferred(True)
+    got = program(dctx)
+    ref_t = O.batchnorm2d(O.relu(O.conv2d(x, w, 1, 1)), bw, bb, bm, bv)
+    assert np.abs(want[0] - ref_t).max() <= 3e-5
+    for g, wnt in zip(got, want):
+        assert np.array_equal(g, wnt)
+
+
+def test_observation_rules(dctx):
+    """What is read is NCHW, whatever the buffer holds: whole-tensor copies (the buffer stays NHWC), partial
+    copies and device-to-device copies (the buffer is rewritten first), rn_observe; writes into a recorded
+    operand run the list first; a free with recorded ops pending; rewritten batch-norm parameters and
+    weights are folded / packed again."""
+    B, C, H, W = 2, 64, 6, 6
+    x, w = rnd((B, C, H, W), 11), rnd((C, C, 1, 1), 12, 0.12)
+    bw, bb, bm, bv = bn_params(C, 13)
+    dx, dw = gpu(x), gpu(w)
+    P = [gpu(v) for v in (bw, bb, bm, bv)]
+    out = R.FloatTensor((B, C, H, W), R.Device.GPU)
+    n = B * C * H * W
+
+    def run():
+        call(dctx, "rn_conv2d_forward", dx.data(), out.data(), dw.data(), 1, 1, 0, H, W, B, C, C, H, W)
+        call(dctx, "rn_batchnorm2d_forward", out.data(), out.data(), *(q.data() for q in P), B, C, H * W)
+        call(dctx, "rn_relu_forward", out.data(), out.data(), n)
+
+    want = O.relu_(O.batchnorm2d_(O.conv2d(x, w, 1, 0), bw, bb, bm, bv))
+    run()
+    whole = out.numpy()
+    assert np.abs(whole - want).max() <= 1e-5 and dctx.deferred_stats()["nhwc_buffers"] >= 1
+    # a partial read: the second image only
+    host = np.empty(C * H * W, dtype=np.float32)
+    call(dctx, "rn_memcpy_d2h", host.ctypes.data, out.data() + C * H * W * 4, C * H * W * 4)
+    assert np.array_equal(host.reshape(C, H, W), whole[1])
+    assert np.array_equal(out.numpy(), whole)
+    # device-to-device copy of a tagged buffer
+    run()
+    twin = R.FloatTensor((B, C, H, W), R.Device.GPU)
+    call(dctx, "rn_memcpy_d2d", twin.data(), out.data(), n * 4)
+    assert np.array_equal(twin.numpy(), whole)
+    # rn_observe: the caller's own kernels may read the pointer afterwards (here: a raw hipMemcpy via torch-free d2h)
+    run()
+    dctx.observe(out.data())
+    assert dctx.deferred_stats()["pending_ops"] == 0
+    t0 = dctx.deferred_stats()["transposes"]
+    assert np.array_equal(out.numpy(), whole) and dctx.deferred_stats()["transposes"] == t0
+    # a write into the input while ops that read it are recorded: they run first, on the old content
+    run()
+    x2 = rnd((B, C, H, W), 14)
+    call(dctx, "rn_memcpy_h2d", dx.data(), x2.ctypes.data, n * 4)
+    assert np.array_equal(out.numpy(), whole)
+    run()
+    want2 = O.relu_(O.batchnorm2d_(O.conv2d(x2, w, 1, 0), bw, bb, bm, bv))
+    assert np.abs(out.numpy() - want2).max() <= 1e-5
+    # new batch-norm parameters in the same buffers: folded again, not taken from the cache
+    bw2 = (bw * 2).astype(np.float32)
+    call(dctx, "rn_memcpy_h2d", P[0].data(), bw2.ctypes.data, C * 4)
+    run()
+    want3 = O.relu_(O.batchnorm2d_(O.conv2d(x2, w, 1, 0), bw2, bb, bm, bv))
+    assert np.abs(out.numpy() - want3).max() <= 1e-5
+    # new weights in the same buffer: packed again
+    w2 = rnd((C, C, 1, 1), 15, 0.12)
+    call(dctx, "rn_memcpy_h2d", dw.data(), w2.ctypes.data, w2.nbytes)
+    run()
+    want4 = O.relu_(O.batchnorm2d_(O.conv2d(x2, w2, 1, 0), bw2, bb, bm, bv))
+    assert np.abs(out.numpy() - want4).max() <= 1e-5
+    # memset over a tagged buffer, then a read: zeros, and the tag is gone
+    run()
+    dctx.flush()
+    call(dctx, "rn_memset", out.data(), 0, n * 4)
+    assert not out.numpy().any()
+    # a free while ops that name the buffer are recorded
+    tmp = R.FloatTensor((B, C, H, W), R.Device.GPU)
+    call(dctx, "rn_conv2d_forward", dx.data(), tmp.data(), dw.data(), 1, 1, 0, H, W, B, C, C, H, W)
+    call(dctx, "rn_relu_forward", tmp.data(), out.data(), n)
+    del tmp
+    assert dctx.deferred_stats()["pending_ops"] == 0
+    assert np.abs(out.numpy() - O.relu(O.conv2d(x2, w2, 1, 0))).max() <= 1e-5
+    # entry points outside the seven see NCHW: the layout converter on a tagged buffer
+    run()
+    dctx.flush()
+    nhwc = R.FloatTensor((B, H, W, C), R.Device.GPU)
+    call(dctx, "rn_nchw_to_nhwc", out.data(), nhwc.data(), B, C, H, W)
+    assert np.abs(nhwc.numpy().transpose(0, 3, 1, 2) - want4).max() <= 1e-5
+
+
+def _build(tmp_path, name):
+    exe = str(tmp_path / name)
+    libdir = os.path.dirname(R._lib.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", f"-I{ROOT}/include", f"{ROOT}/examples/{name}.cpp",
+                    f"-L{libdir}", "-lrn_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                   check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_cpp_veneer_is_deferred_by_default_and_literal_on_request(tmp_path, state50, finch, golden_dir):
+    """examples/resnet_veneer.cpp (reference-named C++ classes, tensors allocated and freed per block): the
+    veneer's context is deferred unless RN_VENEER_LITERAL=1.  Both within the bar of the goldens, the same
+    class indices; the literal run is the op-by-op mode of the model driver to 1e-5."""
+    exe = _build(tmp_path, "resnet_veneer")
+    os.mkdir(tmp_path / "weights_bin")
+    R.weights.save_weights_bin(state50, str(tmp_path / "weights_bin"))
+    x = np.concatenate([finch, R.weights.generate_input(1, seed=7)[:1]]).astype(np.float32)
+    x.tofile(tmp_path / "input.bin")
+    outs = {}
+    for mode, env in (("deferred", {}), ("literal", {"RN_VENEER_LITERAL": "1"})):
+        r = subprocess.run([exe, "50", "input.bin", f"logits_{mode}.bin"], cwd=tmp_path, capture_output=True,
+                           text=True, timeout=300, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr
+        outs[mode] = np.fromfile(tmp_path / f"logits_{mode}.bin", dtype=np.float32).reshape(2, 1000)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("max index is")]
+        assert lines == [f"max index is {int(outs[mode][0].argmax())}", f"max index is {int(outs[mode][1].argmax())}"]
+    want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
+    for mode in outs:
+        assert np.abs(outs[mode][:1] - want).max() <= 1e-4 and int(outs[mode][0].argmax()) == 112
+    assert np.abs(outs["deferred"] - outs["literal"]).max() <= 5e-5
+    assert np.array_equal(outs["deferred"].argmax(1), outs["literal"].argmax(1))
+    m = R.NativeModel("resnet50", state=state50)
+    try:
+        assert np.abs(m.forward(x, fused=False) - outs["literal"]).max() <= 1e-5
+    finally:
+        m.close()

@@ -103,14 +103,15 @@ def test_veneer_runs_and_matches_oracle(tmp_path):
 def test_whole_network_through_the_veneer(tmp_path, state50, finch, golden_dir):
     """examples/resnet_veneer.cpp: ResNet-50 built from the reference-named C++ classes, loading
     weights_bin/<key> files, one veneer call (= one C-ABI call, NCHW, synchronous) per reference
-    op.  Same logits as the reference module's goldens, same 'max index is N' line."""
+    op -- the literal route (RN_VENEER_LITERAL=1; the deferred default is tests/test_defer_gpu.py's).
+    Same logits as the reference module's goldens, same 'max index is N' line."""
     exe = _build(tmp_path, "resnet_veneer")
     os.mkdir(tmp_path / "weights_bin")
     R.weights.save_weights_bin(state50, str(tmp_path / "weights_bin"))
     x = np.concatenate([finch, R.weights.generate_input(1, seed=7)[:1]]).astype(np.float32)
     x.tofile(tmp_path / "input.bin")
     r = subprocess.run([exe, "50", "input.bin", "logits.bin"], cwd=tmp_path, capture_output=True,
-                       text=True, timeout=300)
+                       text=True, timeout=300, env={**os.environ, "RN_VENEER_LITERAL": "1"})
     assert r.returncode == 0, r.stderr
     got = np.fromfile(tmp_path / "logits.bin", dtype=np.float32).reshape(2, 1000)
     want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))

@@ -35,6 +35,15 @@ CUS, SIMDS, XCDS = 256, 4, 8
 
 
 def short(name):
+    """rocprofv3 leaves names with a bf16 template argument mangled (_ZN12_GLOBAL__N_116conv_wide_kernelIDF16bLi224E...)."""
+    import re
+    m = re.match(r"_ZN12_GLOBAL__N_1\d+([a-z0-9_]+?)I(.*?)EEvN", name)
+    if m:
+        args = []
+        for a in re.findall(r"DF16b|Li\d+E|Lb[01]E|f", m.group(2)):
+            args.append("bf16" if a == "DF16b" else "float" if a == "f" else a[2:-1] if a[1] == "i" else
+                        ("true" if a[2] == "1" else "false"))
+        return f"{m.group(1)}<{', '.join(args)}>"
     n = name.replace("void ", "").replace("(anonymous namespace)::", "").replace("rn_gemm::", "")
     return n.split("(")[0][:110]
 

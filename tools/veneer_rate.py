@@ -33,6 +33,32 @@ for sync, cache in (((False, False),) if a.route_only else ((True, False), (Fals
           f"{dt*1e3:8.2f} ms/forward  {a.batch/dt:8.1f} img/s")
 if a.route_only:
     sys.exit(0)
+# the same unchanged caller on a deferred context (rn_ctx_set_deferred: what the C++ veneer runs by default):
+# every call is recorded; the list runs when the logits are observed, conv + in-place bn / add / relu as one
+# fused NHWC launch in the caller's own buffers
+ctx.set_sync_each_op(False)
+ctx.set_weight_cache(True)
+ctx.set_deferred(True)
+for _ in range(3):
+    out = R.resnetForward(m, x)
+    ctx.flush()
+ctx.sync()
+s0 = ctx.deferred_stats()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    out = R.resnetForward(m, x)
+    ctx.flush()
+ctx.sync()
+dt = (time.perf_counter() - t0) / a.steps
+s1 = ctx.deferred_stats()
+per = {k: (s1[k] - s0[k]) // a.steps for k in ("fused_launches", "literal_launches", "transposes")}
+print(f"NCHW op-by-op graph, DEFERRED (conv + in-place bn / add / relu folded, NHWC kept in the caller's buffers): "
+      f"{dt*1e3:8.2f} ms/forward  {a.batch/dt:8.1f} img/s   per forward: {per}")
+logits_deferred = out.numpy()
+ctx.set_deferred(False)
+logits_literal = R.resnetForward(m, x).numpy()
+print(f"   max |deferred - literal| over the logits: {np.abs(logits_deferred - logits_literal).max():.2e}, "
+      f"same top-1 on {int((logits_deferred.argmax(1) == logits_literal.argmax(1)).sum())} of {a.batch}")
 ctx.set_sync_each_op(False)
 ctx.set_weight_cache(False)
 nm = R.NativeModel("resnet50", state=state)
