@@ -156,6 +156,13 @@ RN_API int rn_ctx_set_split_k(rn_ctx *ctx, int max_splits);
  * blocks fill the device's CUs in the fewest rounds.  The bits do not depend on it: a block that
  * starts inside an image computes the one stem row above its segment once more. */
 RN_API int rn_ctx_set_stem_items(rn_ctx *ctx, int items);
+/* Tile order of the fp32 / bf16 4-wave contraction over the 8 XCDs (each with an L2 of its own): the tiles
+ * are dealt as contiguous ranges of an order that keeps an XCD to one of `groups` groups of N tiles -- its
+ * slice of the weight panel stays in that L2 while the M panels go by, the input is fetched by `groups`
+ * XCDs.  0 (default): chosen per launch from the sizes of the input and of the weight panel; 1: M panel
+ * major (an XCD reads its input rows once and streams the whole weight panel); 2 / 4 / 8: forced (also
+ * RN_XCD_NGROUPS in the environment at context creation).  Changes which block computes a tile, no bit. */
+RN_API int rn_ctx_set_xcd_groups(rn_ctx *ctx, int groups);
 /* Diagnostics: device buffer of 16 x uint64 per block that the contraction kernel fills with
  * wall-clock and shader-clock stamps of its phases (tools/conv_stamps.py); NULL (default) = off. */
 RN_API int rn_ctx_set_debug_stamps(rn_ctx *ctx, void *dev_buffer);

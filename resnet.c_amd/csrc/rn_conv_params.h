@@ -35,6 +35,14 @@ struct GemmParams {
     int nk;         // K tiles
     int tiles_n;
     unsigned total_tiles;  // the grid may be smaller: blocks then walk tiles grid-stride
+    // tile order (rn_conv.hip, conv_gemm_kernel): the tiles the remap covers are dealt to the 8 XCDs as
+    // contiguous ranges of an ORDER; xg = 0: the order is the logical one (M panel major, the N tiles of a
+    // panel adjacent: an XCD reads its A panels once and streams the whole weight panel);  xg > 0: the order
+    // is (N group of xg tiles, M panel, N tile in the group) over the first xrows whole rows of M panels, so
+    // that an XCD keeps to one group of N tiles -- a slice of the weight panel small enough to stay in its
+    // 4 MB L2 while M advances -- and the A panels are read by tiles_n / xg XCDs instead
+    int xg;
+    unsigned xrows;
     int HoWo;
     unsigned mul_hw, shr_hw, mul_w, shr_w;  // n / d == umulhi(n, mul) >> shr for n < 2^31
     unsigned mul_cs, shr_cs, mul_kw, shr_kw;  // K tile -> (tap, segment), tap -> (kh, kw)

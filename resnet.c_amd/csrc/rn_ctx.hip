@@ -205,6 +205,10 @@ int rn_ctx_create(rn_ctx **out, int device, void *hip_stream)
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) ctx->cus = v;
     }
     ctx->layout = RN_LAYOUT_NCHW;
+    if (const char *xg = getenv("RN_XCD_NGROUPS")) {  // A/B runs of the tile order (tools/tile_fetch_ab.sh)
+        const int g = atoi(xg);
+        if (g == 1 || g == 2 || g == 4 || g == 8) ctx->xcd_groups = g;
+    }
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
         ctx->own_stream = false;
@@ -280,6 +284,15 @@ int rn_ctx_set_split_k(rn_ctx *ctx, int max_splits)
     if (max_splits < 0 || max_splits > 64)
         return rn_set_error(ctx, RN_ERR_INVALID, "split_k %d out of range [0, 64]", max_splits);
     ctx->split_k = max_splits <= 1 ? 0 : max_splits;
+    return RN_OK;
+}
+
+int rn_ctx_set_xcd_groups(rn_ctx *ctx, int groups)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (groups != 0 && groups != 1 && groups != 2 && groups != 4 && groups != 8)
+        return rn_set_error(ctx, RN_ERR_INVALID, "xcd groups %d: 0 (chosen per launch), 1, 2, 4 or 8", groups);
+    ctx->xcd_groups = groups;
     return RN_OK;
 }
 
