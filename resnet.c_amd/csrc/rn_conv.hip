@@ -871,13 +871,20 @@ void launch_tiles_chunked(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool
 }
 
 // Which order the tiles are dealt to the XCDs in (GemmParams::xg).  Every XCD has its own 4 MB L2; what an
-// L2 misses comes from the Infinity Cache or HBM and is what FETCH_SIZE counts.  With N_g groups of N tiles
-// (N_g = tiles_n / xg) an XCD keeps to one group: the A panels are fetched by N_g XCDs (N_g x the input) and
-// every XCD fetches its slice of the weight panel (8 / N_g x the panel in total) -- once if the slice stays in
-// L2 while the M panels go by, again and again if it does not (stage 4 of ResNet-50 in the logical order:
-// 9.4 MB of 3x3 weights streamed through every L2 by blocks that drift apart, 530-670 MB fetched for 60 MB).
+// L2 misses comes from the Infinity Cache or HBM and is what FETCH_SIZE counts.  The blocks resident on an XCD
+// (R = 32 CUs x the tile's blocks per CU) work on nt N tiles x R / nt M panels at a time and need
+// nt weight-row slabs (BN x K) and R / nt input slabs (BM x Cin) over and over while their K loops run:
+// when that working set fits the L2, the launch fetches about G x the input + 8 / G x the weight panel
+// (G groups of N tiles: an XCD keeps to one group, the input rows are read by G XCDs); when it does not, blocks
+// that have drifted apart in K evict each other's rows and the launch fetches several times that.
+// Measured on the stage 3-4 shapes at B = 256 (tools/xcd_order_ab.sh, profiles/round4/xcd_tile_order_ab.txt):
+// layer4 conv3 (K = 512, N = 2048: 4.2 MB of weights) 430-630 MB in the logical order, 81-91 MB in two groups
+// (algorithmic 30 MB + the output), 113 in four, 214 in eight; every other shape either fits in the logical
+// order already (256 -> 1024 at 14 x 14: 60 MB for 52) or fits in NO grouping (3 x 3 with 512 channels: a slab
+// of weight rows is 1.2 MB, 128 resident blocks need 17 MB of input slabs in the grouped orders -- 532 MB
+// logical, 454 / 839 / 1545 in 2 / 4 / 8 groups), and there the logical order stays.
 // The order changes which block computes a tile, never a bit of the result.
-void choose_tile_order(rn_ctx *ctx, GemmParams &p, unsigned remap_tiles)
+void choose_tile_order(rn_ctx *ctx, GemmParams &p, unsigned remap_tiles, int BM, int BN)
 {
     p.xg = 0;
     p.xrows = 0;
@@ -885,17 +892,25 @@ void choose_tile_order(rn_ctx *ctx, GemmParams &p, unsigned remap_tiles)
     if (tn < 2 || remap_tiles < 8 * tn) return;  // too few rows of M panels for eight ranges per group
     int groups = ctx->xcd_groups;                // forced (RN_XCD_NGROUPS / rn_ctx_set_xcd_groups): A/B runs
     if (groups <= 0) {
-        const double A = (double)p.in_bytes + (double)p.in2_bytes, Wb = (double)p.w_bytes, L2 = 4.0 * 1024 * 1024;
-        double best = 1e300;
+        const double es = p.w_bytes / ((double)p.Cout * p.Ktot);  // bytes per element
+        const double w_slab = (double)BN * p.Ktot * es;           // weight rows of one N tile
+        const double a_slab = (double)BM * es * (p.Cs + (p.in2 ? p.Cs2 : 0));    // input rows of one M panel
+        const double R = 32.0 * (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 ? 3 : 2);
+        const double A = (double)p.in_bytes + (p.in2 ? (double)p.in2_bytes : 0.0), Wb = (double)p.w_bytes;
+        const double L2 = 3.8 * 1024 * 1024;  // of 4 MB (measured: a 3.7 MB set still holds)
+        auto fits = [&](int g) {
+            const double nt = (double)tn / g, mp = R / nt < 1 ? 1 : R / nt;
+            return nt * w_slab + mp * a_slab <= L2;
+        };
         groups = 1;
-        for (int g = 1; g <= 8; g *= 2) {
-            if (tn % (unsigned)g) break;
-            const double slice = Wb / g;
-            // a slice that fills more than a third of an L2 is evicted by the A and output streams between
-            // two visits: it is fetched once per generation of resident tiles rather than once
-            const double again = slice <= L2 / 3 ? 1.0 : 1.0 + 6.0 * (slice - L2 / 3) / L2;
-            const double cost = g * A + 8.0 * slice * (again > 8.0 ? 8.0 : again);
-            if (cost < best * 0.97) best = cost, groups = g;
+        if (!fits(1)) {
+            double best = 1e300;
+            for (int g = 2; g <= 8; g *= 2) {
+                if (tn % (unsigned)g) break;
+                if (!fits(g)) continue;
+                const double cost = g * A + 8.0 * Wb / g;
+                if (cost < best) best = cost, groups = g;
+            }
         }
     }
     if (groups > 8) groups = 8;
@@ -1170,7 +1185,7 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
             p.total_work = p.full_tiles + tail * (unsigned)S;
         }
         p.grid_items = p.total_work;
-        choose_tile_order(ctx, p, p.full_tiles);
+        choose_tile_order(ctx, p, p.full_tiles, BMsel, BNsel);
         launch_tiles_chunked(ctx, p, BMsel, BNsel, persistent);
         RN_TRY(rn_after_launch(ctx, what));
         if (cut) {
@@ -1192,7 +1207,7 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     }
 
     p.grid_items = p.total_tiles;
-    choose_tile_order(ctx, p, p.total_tiles);
+    choose_tile_order(ctx, p, p.total_tiles, BMsel, BNsel);
     if (exact)
         launch_tiles<float, float, false, true>(ctx, p, BMsel, BNsel, persistent);
     else if (second && dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32)

@@ -85,6 +85,11 @@ class Context:
         return dict(zip(("pending_ops", "nhwc_buffers", "fused_launches", "literal_launches", "transposes"),
                         (int(x.value) for x in v)))
 
+    def set_xcd_groups(self, groups: int) -> None:
+        """Tile order of the contraction over the 8 XCDs: 0 = chosen per launch, 1 = M panel major, 2 / 4 / 8 groups
+        of N tiles (rn_ctx_set_xcd_groups).  Changes which block computes a tile, never a bit."""
+        L.check(L.lib().rn_ctx_set_xcd_groups(self.handle, int(groups)), "rn_ctx_set_xcd_groups", self.handle)
+
     def set_weight_cache(self, on: bool) -> None:
         """rn_conv2d_forward (OIHW weights) packs each weight buffer once instead of per call."""
         L.check(L.lib().rn_ctx_set_weight_cache(self.handle, int(on)), "rn_ctx_set_weight_cache")

@@ -838,3 +838,40 @@ def test_nchw_native_1x1_random_shapes(seed):
     assert np.array_equal(a, ops.conv2d(x, w, stride, 0, "nhwc")), (B, Cin, Cout, H, W, stride)
     want = O.conv2d(x, w, stride, 0)
     assert np.abs(a - want).max() <= 2e-6 * np.sqrt(Cin) * float(np.abs(want).max()) + 1e-6
+
+
+@pytest.mark.parametrize("case", [(16, 7, 7, 512, 2048, 1, 1, 0),     # layer4 conv3: the shape the per-launch rule groups
+                                  (9, 14, 14, 256, 256, 3, 1, 1),     # chunked K sum with a cut tail behind the remap
+                                  (5, 9, 11, 64, 320, 1, 1, 0),       # ragged: 5 N tiles (no grouping possible), ragged M
+                                  (7, 13, 13, 96, 256, 3, 2, 1),      # whole rows + a partial last row of M panels
+                                  (3, 28, 28, 128, 512, 1, 1, 0)])
+def test_xcd_tile_order_changes_blocks_not_bits(case):
+    """rn_ctx_set_xcd_groups: the tiles are dealt to the XCDs in 1 / 2 / 4 / 8 groups of N tiles (a bijection of
+    the tile index for any tile count: whole rows of M panels are reordered, the tiles past them keep their
+    place).  Every order, on every 4-wave tile candidate, writes the bits of the logical order; against the oracle
+    once."""
+    from resnet_c_amd import _lib as L
+    B, H, W, Cin, Cout, k, s, p = case
+    x, w = rnd((B, Cin, H, W), 40 + sum(case)), rnd((Cout, Cin, k, k), 41 + sum(case)) / np.sqrt(Cin * k * k)
+    g = np.random.default_rng(42 + sum(case))
+    sc, sh = g.random(Cout, dtype=np.float32) + 0.5, g.standard_normal(Cout, dtype=np.float32)
+    ctx, lib = R.get_ctx(), L.lib()
+    try:
+        ctx.set_xcd_groups(1)
+        lib.rn_ctx_set_conv_tile(ctx.handle, 4)
+        want = ops.conv2d_nhwc_fused(x, w, s, p, sc, sh, None, True)
+        for groups in (0, 1, 2, 4, 8):
+            ctx.set_xcd_groups(groups)
+            for cand in (1, 2, 3, 4, 6, 8):
+                lib.rn_ctx_set_conv_tile(ctx.handle, cand)
+                got = ops.conv2d_nhwc_fused(x, w, s, p, sc, sh, None, True)
+                assert np.array_equal(got, want), (groups, cand)
+    finally:
+        ctx.set_xcd_groups(0)
+        lib.rn_ctx_set_conv_tile(ctx.handle, 0)
+    y = O.conv2d(x, w, s, p)
+    ref = np.maximum(y * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    assert np.abs(want - ref).max() <= 3e-6 * np.sqrt(Cin * k * k) * float(np.abs(ref).max()) + 1e-5
+    with pytest.raises(L.RnError):
+        ctx.set_xcd_groups(3)
+

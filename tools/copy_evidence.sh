@@ -21,6 +21,7 @@ if [ $what = mfma ]; then
     src=$o/pmc_mfma_utilisation_${pair%%:*}
     [ -f $src.json ] && cp $src.json $d/final_pmc_mfma_utilisation${pair##*:}.json
     [ -f $src.per_kernel.txt ] && cp $src.per_kernel.txt $d/pmc_mfma_utilisation_per_kernel_${pair%%:*}.txt
+    [ -f $src.per_layer.txt ] && cp $src.per_layer.txt $d/pmc_mfma_utilisation_per_layer_${pair%%:*}.txt
   done
 fi
 if [ $what = bench ]; then

@@ -83,12 +83,13 @@ if [ $what = pmc ] || [ $what = all ]; then
 fi
 if [ $what = mfma ] || [ $what = all ]; then
   # matrix-pipe utilisation of every contraction instantiation: one SQ pass (8 SQ slots + GRBM), program right after --
-  rm -rf $o/mfma.stamp $o/mfma_f32 $o/mfma_bf16 $o/pmc_mfma_utilisation_*
+  rm -rf $o/mfma.stamp $o/mfma_f32 $o/mfma_bf16 $o/pmc_mfma_utilisation_* $o/mfma_layers_*
   for dt in f32 bf16; do
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
       --output-format csv -d $o/mfma_$dt -- python3 bench.py --dtype $dt --streams 1 --steps 2 --warmup 1 --profile-forwards 1 --no-cpu-baseline --no-pipeline --no-ops-leg > /dev/null 2> $o/mfma_$dt.err
     ref_line mfma_$dt --dtype $dt
-    python tools/pmc_mfma.py $o/mfma_$dt $o/pmc_mfma_utilisation_$dt.json $n "ResNet-50 $dt B=256 fused, one stream; one rocprofv3 --pmc pass" > $o/mfma_$dt.summary 2>&1
+    python tools/layer_report.py --tune --dtype $dt > $o/mfma_layers_$dt.txt 2> /dev/null
+    python tools/pmc_mfma.py $o/mfma_$dt $o/pmc_mfma_utilisation_$dt.json $n "ResNet-50 $dt B=256 fused, one stream; one rocprofv3 --pmc pass" $o/mfma_layers_$dt.txt > $o/mfma_$dt.summary 2>&1
   done
   find $o -name '*counter_collection.csv' -size +8M -delete
   stamp mfma

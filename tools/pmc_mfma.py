@@ -3,7 +3,10 @@
 (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA
 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE: 8 SQ slots; GRBM_GUI_ACTIVE rides in the GRBM block).
 
-    python tools/pmc_mfma.py <pmc dir> out.json <launches per forward> [note]
+    python tools/pmc_mfma.py <pmc dir> out.json <launches per forward> [note] [layers.txt]
+
+(layers.txt: tools/layer_report.py's table of the same configuration; with it the launches of the forward are also
+written one by one, in order, under their layer names, as <out minus .json>.per_layer.txt)
 
 Uses the contraction dispatches of the LAST forward of the run (as tools/pmc_traffic.py does).  Per kernel
 instantiation and for the family as a whole:
@@ -99,6 +102,32 @@ def main():
                      f"{r.get('mfma_busy_in_busy_cu', 0):10.3f} {r.get('cu_busy', 0):7.3f} {r.get('wait_inst', 0):9.3f} "
                      f"{r.get('wait_any', 0):8.3f} {r.get('lds_conflict', 0):9.3f} {c.get('SQ_INSTS_MFMA', 0):12.0f}   {k}\n")
         fh.write("# kernel_us: GRBM_GUI_ACTIVE / 8 at a nominal 2.4 GHz (the chip holds less under load: durations come from the traces)\n")
+    if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):
+        layers = []
+        for line in open(sys.argv[5]):
+            q = line.split()
+            if len(q) >= 6 and (q[0].startswith("conv2d") or q[0] == "linear"):
+                layers.append((q[1], float(q[2]), float(q[3])))  # name, ms by events, TFLOP/s
+        groups = []  # a splitk_finish_kernel belongs to the launch in front of it
+        for e in rows:
+            if "splitk_finish" in e["name"] and groups:
+                for k, v in e["c"].items():
+                    groups[-1]["c"][k] += v
+                groups[-1]["name"] += " +finish"
+            else:
+                groups.append({"name": short(e["name"]), "c": collections.defaultdict(float, e["c"])})
+        with open(os.path.splitext(out_path)[0] + ".per_layer.txt", "w") as fh:
+            if len(groups) != len(layers):
+                fh.write(f"# {len(groups)} contraction launches against {len(layers)} table rows: names not attached\n")
+                layers = [("?", 0.0, 0.0)] * len(groups)
+            fh.write("# one forward, launch by launch; ms / TF/s: HIP events of an un-profiled run (tools/layer_report.py)\n")
+            fh.write(f"{'layer':42s} {'ms':>6s} {'TF/s':>6s} {'mfma_busy':>9s} {'in_busy_cu':>10s} {'cu_busy':>7s} {'wait_inst':>9s} "
+                     f"{'wait_any':>8s} {'lds_confl':>9s}  kernel\n")
+            for (name, ms, tf), g in zip(layers, groups):
+                r = ratios(g["c"])
+                fh.write(f"{name:42s} {ms:6.3f} {tf:6.1f} {r.get('mfma_busy', 0):9.3f} {r.get('mfma_busy_in_busy_cu', 0):10.3f} "
+                         f"{r.get('cu_busy', 0):7.3f} {r.get('wait_inst', 0):9.3f} {r.get('wait_any', 0):8.3f} "
+                         f"{r.get('lds_conflict', 0):9.3f}  {g['name']}\n")
     r = ratios(total)
     out = {"kernel": " + ".join(FAMILY), "launches": len(rows), "source_digest": source_digest(),
            "mfma_busy": round(r.get("mfma_busy", 0.0), 4),
