@@ -545,12 +545,24 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 
         } else {
             // bf16 (latency-bound): the compact loop keeps the register count, and with it the
             // number of resident blocks, where the unrolled form costs 10 % throughput
+            [[maybe_unused]] int fold_at = kb + p.chunk_L;
+            [[maybe_unused]] bool folded = false;
             for (int kt = kb; kt < ke; ++kt) {
+                if constexpr (CHUNK) {
+                    if (kt == fold_at) {  // uniform; only whole tiles get here (a piece is one chunk)
+                        fold_acc(folded);
+                        folded = true;
+                        fold_at += p.chunk_L;
+                    }
+                }
                 const bool more = kt + 1 < ke;
                 if (more) load_tile(kt + 1, ra, rb, std::false_type{});
                 compute_tile((kt - kb) & 1);
                 if (more) store_tile((kt - kb + 1) & 1, ra, rb);
                 __syncthreads();
+            }
+            if constexpr (CHUNK) {
+                if (folded) finish_acc();
             }
         }
         // next tile of this block: its first K tile starts travelling before the epilogue
@@ -859,10 +871,13 @@ void launch_tiles(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persist
         launch_one<T, TO, 64, 64, DUAL, XK>(ctx, p, persistent);
 }
 
-// chunked K sum (fp32 only; the 128x128 tile has no registers to spare for a second accumulator)
-void launch_tiles_chunked(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent)
+// chunked K sum (fp32, and bf16 operands with an fp32 result: the fc of a bf16 model; the 128x128 tile has
+// no registers to spare for a second accumulator)
+void launch_tiles_chunked(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool persistent, bool bf16_in)
 {
-    if (BMsel == 128)
+    if (bf16_in)
+        launch_one<bf16_t, float, 64, 64, false, false, true>(ctx, p, persistent);
+    else if (BMsel == 128)
         launch_one<float, float, 128, 64, false, false, true>(ctx, p, persistent);
     else if (BNsel == 128)
         launch_one<float, float, 64, 128, false, false, true>(ctx, p, persistent);
@@ -931,6 +946,8 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     const int es = dt_in == RN_DTYPE_BF16 ? 2 : 4;
     const int bke = 128 / es;
     GemmParams p;
+    p.xg = 0;  // tile order: the logical one unless choose_tile_order says otherwise (tiled launches only)
+    p.xrows = 0;
     // NCHW output: fp32, no residual (it would be NHWC); a 1x1 output image is the same in both
     p.out_nchw = out_nchw && dt_out == RN_DTYPE_F32 && !(ep && ep->residual) && h_out * w_out > 1;
     p.in = inp;
@@ -1082,9 +1099,13 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     }
     // Chunked K sum: a property of the LAYER (element type, kind, K), never of the batch size or
     // the tile, so that every launch of the layer adds the same products in the same order.
-    const bool chunked = dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32 && !second && !exact &&
+    // (bf16 operands with fp32 results: the fc of a bf16 model -- 64 tiles of 32 K steps at B = 256, 30 us as
+    // one block per tile on a quarter of the CUs)
+    const bool chunk_bf16 = dt_in == RN_DTYPE_BF16 && dt_out == RN_DTYPE_F32;
+    const bool chunked = ((dt_in == RN_DTYPE_F32 && dt_out == RN_DTYPE_F32) || chunk_bf16) && !second && !exact &&
                          p.nk >= 32 && Cout % 4 == 0;  // (nk >= 16 measured: -0.3 % on the fp32 step)
     if (chunked && BMsel == 128 && BNsel == 128) BNsel = 64;
+    if (chunked && chunk_bf16) BMsel = BNsel = 64;
     const uint64_t tiles_n = rn_ceil_div(Cout, BNsel);
     const uint64_t tiles_m = rn_ceil_div((uint64_t)p.M, BMsel);
     p.tiles_n = (int)tiles_n;
@@ -1157,7 +1178,7 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
     if (chunked) {
         // eight chunks (the last may be shorter; measured: as fast as four at B=256, 11 % less
         // B=1 latency), chunk length even for the two-tile loop trips
-        p.chunk_L = 2 * (int)rn_ceil_div((uint64_t)p.nk, 16);
+        p.chunk_L = 2 * (int)rn_ceil_div((uint64_t)p.nk, 16);  // (even: the fp32 loop takes two K tiles per trip)
         const int S = (int)rn_ceil_div((uint64_t)p.nk, (uint64_t)p.chunk_L);
         // tail = the tiles past the last full round of the 256 CUs, in whole rows of M tiles;
         // cutting them into S pieces pays when the pieces need fewer CU rounds than S
@@ -1186,7 +1207,7 @@ int launch_gemm(rn_ctx *ctx, int dt_in, int dt_out, const void *inp, void *out, 
         }
         p.grid_items = p.total_work;
         choose_tile_order(ctx, p, p.full_tiles, BMsel, BNsel);
-        launch_tiles_chunked(ctx, p, BMsel, BNsel, persistent);
+        launch_tiles_chunked(ctx, p, BMsel, BNsel, persistent, chunk_bf16);
         RN_TRY(rn_after_launch(ctx, what));
         if (cut) {
             FinishParams f;

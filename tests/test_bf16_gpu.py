@@ -483,3 +483,25 @@ def test_bf16_model_agrees_with_fp32_model(state50, finch, golden_dir):
     finally:
         m32.close()
         m16.close()
+
+
+def test_bf16_fc_chunked_k_sum_is_the_same_whole_or_in_pieces():
+    """bf16 operands with an fp32 result (the fc of a bf16 model, [B,2048] x [1000,2048]^T + bias): K = 32
+    tiles is summed as eight chunks, ((c0 + c1) + c2) + ..., like the fp32 layers with K >= 1024.  Tiles
+    computed whole fold the chunks in registers, a launch that cannot fill the chip cuts every tile into
+    (tile, chunk) pieces: the same bits for a row whatever the batch it is in, and the oracle's values on
+    the rounded operands."""
+    K, N = 2048, 1000
+    w = rnd((N, K, 1, 1), 901) / np.sqrt(K)
+    bias = rnd((N,), 902)
+    big = rnd((700, K, 1, 1), 903)                 # 11 x 16 tiles: a few whole rounds would need B > 1024;
+    got = ops.conv2d_nhwc_bf16(big, w, 1, 0, None, bias, None, False, out_f32=True)
+    for lo, hi in ((0, 1), (5, 9), (300, 556), (699, 700)):
+        part = ops.conv2d_nhwc_bf16(big[lo:hi], w, 1, 0, None, bias, None, False, out_f32=True)
+        assert np.array_equal(part, got[lo:hi]), (lo, hi)
+    huge = np.concatenate([big] * 6)[:4100]         # 65 x 16 = 1040 tiles: whole tiles and a cut tail
+    g2 = ops.conv2d_nhwc_bf16(huge, w, 1, 0, None, bias, None, False, out_f32=True)
+    assert np.array_equal(g2[:700], got) and np.array_equal(g2[3500:4100], got[:600])
+    ref = O.conv2d(ops.bf16_round(big[:64]), ops.bf16_round(w), 1, 0) + bias[None, :, None, None]
+    assert np.abs(got[:64] - ref).max() <= 2e-6 * np.sqrt(K) * float(np.abs(ref).max()) + 1e-6
+
