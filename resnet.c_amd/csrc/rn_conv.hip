@@ -894,10 +894,11 @@ void launch_tiles_chunked(rn_ctx *ctx, GemmParams &p, int BMsel, int BNsel, bool
 // that have drifted apart in K evict each other's rows and the launch fetches several times that.
 // Measured on the stage 3-4 shapes at B = 256 (tools/xcd_order_ab.sh, profiles/round4/xcd_tile_order_ab.txt):
 // layer4 conv3 (K = 512, N = 2048: 4.2 MB of weights) 430-630 MB in the logical order, 81-91 MB in two groups
-// (algorithmic 30 MB + the output), 113 in four, 214 in eight; every other shape either fits in the logical
-// order already (256 -> 1024 at 14 x 14: 60 MB for 52) or fits in NO grouping (3 x 3 with 512 channels: a slab
-// of weight rows is 1.2 MB, 128 resident blocks need 17 MB of input slabs in the grouped orders -- 532 MB
-// logical, 454 / 839 / 1545 in 2 / 4 / 8 groups), and there the logical order stays.
+// (algorithmic 30 MB + the output), 113 in four, 214 in eight; 2048 -> 512 at 7 x 7 253 MB logical, 281 in two
+// groups (twice the input for a weight panel that almost fits: not worth it); 256 -> 1024 at 14 x 14 fits in the
+// logical order (60 MB for 52); the 3 x 3 layers with 512 channels fit in NO grouping (a slab of weight rows is
+// 1.2 MB, and 128 resident blocks need 17 MB of input slabs across their nine tap passes in the grouped orders:
+// 532 MB logical, 454 / 839 / 1545 in 2 / 4 / 8 groups) and keep the logical order.
 // The order changes which block computes a tile, never a bit of the result.
 void choose_tile_order(rn_ctx *ctx, GemmParams &p, unsigned remap_tiles, int BM, int BN)
 {
@@ -911,21 +912,31 @@ void choose_tile_order(rn_ctx *ctx, GemmParams &p, unsigned remap_tiles, int BM,
         const double w_slab = (double)BN * p.Ktot * es;           // weight rows of one N tile
         const double a_slab = (double)BM * es * (p.Cs + (p.in2 ? p.Cs2 : 0));    // input rows of one M panel
         const double R = 32.0 * (BM * BN <= 64 * 64 ? 4 : BM * BN <= 64 * 128 ? 3 : 2);
-        const double A = (double)p.in_bytes + (p.in2 ? (double)p.in2_bytes : 0.0), Wb = (double)p.w_bytes;
-        const double L2 = 3.8 * 1024 * 1024;  // of 4 MB (measured: a 3.7 MB set still holds)
-        auto fits = [&](int g) {
+        const double A = (double)p.in_bytes + (p.in2 ? (double)p.in2_bytes / (p.stride2 * p.stride2) : 0.0);
+        const double Wb = (double)p.w_bytes, MB = 1024.0 * 1024.0;
+        const double panels = (double)(remap_tiles / tn);  // M panels of the launch
+        const bool taps = p.KH * p.KW > 1;
+        // bytes a grouping fetches.  A 1x1 convolution streams its input rows once per (M panel, XCD that has
+        // tiles of it) -- the N tiles of a panel are adjacent in the order and run together -- so what has to
+        // stay in the L2 is the group's slice of the weight panel (2.5 of the 4 MB: the input, output and
+        // residual streams pass through as well); a k x k convolution returns to its input rows once per tap,
+        // so the input slabs of the resident M panels have to stay too.  A slice that does not stay is
+        // streamed again by every generation of resident tiles, about three times per generation once the
+        // blocks have drifted apart in K (measured: 4.5 x for 2048 -> 512 at 7 x 7, 12-18 x for 512 -> 2048).
+        auto cost = [&](int g) {
             const double nt = (double)tn / g, mp = R / nt < 1 ? 1 : R / nt;
-            return nt * w_slab + mp * a_slab <= L2;
+            const bool stays = taps ? nt * w_slab + mp * a_slab <= 3.8 * MB : nt * w_slab <= 2.5 * MB;
+            const double generations = panels / (8.0 / g) / mp;
+            const double again = stays ? 1.0 : 3.0 * (generations < 1 ? 1 : generations);
+            if (taps && !stays && g > 1) return 1e300;  // (measured: grouping a thrashing 3x3 only adds input reads)
+            return (g > 1 ? 1.3 : 1.0) * g * A + 8.0 * (Wb / g) * again;
         };
         groups = 1;
-        if (!fits(1)) {
-            double best = 1e300;
-            for (int g = 2; g <= 8; g *= 2) {
-                if (tn % (unsigned)g) break;
-                if (!fits(g)) continue;
-                const double cost = g * A + 8.0 * Wb / g;
-                if (cost < best) best = cost, groups = g;
-            }
+        double best = cost(1);
+        for (int g = 2; g <= 8; g *= 2) {
+            if (tn % (unsigned)g) break;
+            const double c = cost(g);
+            if (c < 0.8 * best) best = c, groups = g;  // (the model is good to about 25 %)
         }
     }
     if (groups > 8) groups = 8;
