@@ -36,3 +36,11 @@ def test_ops_fuzz_short():
 def test_model_fuzz_short(dtype):
     out = run_tool("model_fuzz.py", "--seconds", "8", "--seed", "103", "--dtype", dtype)
     assert "gave the pool's bits" in out
+
+
+def test_defer_fuzz_short():
+    """Random programs of the seven reference ops on a deferred context (folding and non-folding chains, reads,
+    partial reads, rn_observe, writes into operands, frees, parameter updates) against the literal run."""
+    out = run_tool("defer_fuzz.py", "--seconds", "10", "--seed", "104")
+    assert "all within tolerance" in out
+
