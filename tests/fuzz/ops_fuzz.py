@@ -94,8 +94,9 @@ def main():
             m, v = g.standard_normal(C, dtype=np.float32), g.random(C, dtype=np.float32) + 0.5
             want = O.batchnorm2d(x, w, b, m, v)
             got = ops.batchnorm2d(x, w, b, m, v, layout, inplace=bool(g.integers(0, 2)))
-            ulp = np.spacing(np.abs(want).astype(np.float32))
-            assert (np.abs(got - want) <= ulp).all(), f"batchnorm {layout} {x.shape}"
+            # ops.cu:150 type by type in the oracle and in the kernels (fp32 subtraction, then double, one fma, one
+            # rounding): the same bits
+            assert np.array_equal(got, want), f"batchnorm {layout} {x.shape}"
         elif what == "linear":
             B, I, Oo = int(g.integers(1, 70)), int(g.choice([1, 7, 32, 64, 96, 300, 2048])), int(g.integers(1, 130))
             x, w = g.standard_normal((B, I), dtype=np.float32), g.standard_normal((Oo, I), dtype=np.float32) / np.sqrt(I)
@@ -112,7 +113,7 @@ def main():
             inplace = bool(g.integers(0, 2))
             assert np.array_equal(ops.relu(x, inplace), O.relu(x)) and np.array_equal(ops.add(x, y, inplace), O.add(x, y))
         n[what] += 1
-    print(f"ops_fuzz: {n}, seed {a.seed}: pools / relu / add / layout changes bit-exact, batch-norm within 1 ulp, linear within tolerance")
+    print(f"ops_fuzz: {n}, seed {a.seed}: pools / relu / add / batch-norm / layout changes bit-exact, linear within tolerance")
 
 
 if __name__ == "__main__":
