@@ -17,6 +17,9 @@ The JSON line also carries
                 FLOPs of its launches in one forward / their summed HIP-event durations,
                 measured on the library's stream in per-op instrumented forwards run
                 right after the timed region (the timed region itself is uninstrumented);
+                traffic / mfma_busy: HBM bytes per launch and the share of all SIMD cycles with
+                a matrix pipe busy, from the committed rocprofv3 --pmc passes of this command,
+                quoted only for the build they were measured on (source digest);
   hbm_kernels   the same for the bandwidth-bound kernels (GB/s against 8 TB/s): those of the timed
                 (fused) forward plus, from a short leg in the one-kernel-per-reference-op mode run
                 after the timed region, batch-norm / ReLU / add / max-pool;
