@@ -130,6 +130,54 @@ int materialise(rn_ctx *ctx, const void *ptr)
     return RN_OK;
 }
 
+// An operand that lies INSIDE a tagged buffer without being that buffer -- a batch slice, a sub-view at an
+// offset, an output that covers only part of it -- is NCHW arithmetic on the caller's side: the buffer gets its
+// NCHW content back first.  (An operand that IS a tagged buffer, base and size, is the ops' own business.)
+int settle(rn_ctx *ctx, const void *ptr, uint64_t bytes)
+{
+    rn_defer_state *ds = ctx->ds;
+    if (!ptr || !bytes) return RN_OK;
+    for (size_t i = 0; i < ds->tags.size();) {
+        const Tag t = ds->tags[i];
+        const uint64_t tb = t.numel() * sizeof(float);
+        if (overlaps(ptr, bytes, t.ptr, tb) && !(t.ptr == ptr && tb == bytes)) {
+            RN_TRY(materialise(ctx, t.ptr));
+            i = 0;
+        } else {
+            ++i;
+        }
+    }
+    return RN_OK;
+}
+
+int settle_op(rn_ctx *ctx, const Op &o)
+{
+    const uint64_t f = sizeof(float);
+    switch (o.kind) {
+    case K_CONV:
+        RN_TRY(settle(ctx, o.in, o.B * o.Cin * o.H * o.W * f));
+        return settle(ctx, o.out, o.B * o.Cout * o.ho * o.wo * f);
+    case K_BN:
+        RN_TRY(settle(ctx, o.in, o.B * o.Cout * o.N * f));
+        return settle(ctx, o.out, o.B * o.Cout * o.N * f);
+    case K_RELU:
+        RN_TRY(settle(ctx, o.in, o.N * f));
+        return settle(ctx, o.out, o.N * f);
+    case K_ADD:
+        RN_TRY(settle(ctx, o.in, o.N * f));
+        RN_TRY(settle(ctx, o.in2, o.N * f));
+        return settle(ctx, o.out, o.N * f);
+    case K_MAXPOOL:
+    case K_AVGPOOL:
+        RN_TRY(settle(ctx, o.in, o.B * o.Cout * o.H * o.W * f));
+        return settle(ctx, o.out, o.B * o.Cout * o.ho * o.wo * f);
+    case K_LINEAR:
+        RN_TRY(settle(ctx, o.in, o.B * o.Cin * f));
+        return settle(ctx, o.out, o.B * o.Cout * f);
+    }
+    return RN_OK;
+}
+
 int fold_for(rn_ctx *ctx, const Op &bn, const float **scale, const float **shift)
 {
     rn_defer_state *ds = ctx->ds;
@@ -232,6 +280,9 @@ int run_conv(rn_ctx *ctx, size_t i, size_t *next)
     if (j < n && ds->ops[j].kind == K_RELU && ds->ops[j].in == c.out && ds->ops[j].out == c.out &&
         ds->ops[j].N == numel)
         relu = &ds->ops[j++];
+    if (bn) RN_TRY(settle_op(ctx, *bn));      // (in place on c.out: nothing to do unless it overlaps another buffer)
+    if (add) RN_TRY(settle_op(ctx, *add));    // the residual may be a slice of a tagged buffer
+    if (relu) RN_TRY(settle_op(ctx, *relu));
     rn_epilogue ep;
     memset(&ep, 0, sizeof(ep));
     if (bn) RN_TRY(fold_for(ctx, *bn, &ep.scale, &ep.shift));
@@ -363,6 +414,8 @@ int run_list(rn_ctx *ctx)
     int st = RN_OK;
     size_t i = 0;
     while (st == RN_OK && i < ds->ops.size()) {
+        st = settle_op(ctx, ds->ops[i]);
+        if (st != RN_OK) break;
         if (ds->ops[i].kind == K_CONV) {
             size_t next = i + 1;
             st = run_conv(ctx, i, &next);

@@ -50,6 +50,16 @@ static int run_sharded(const int *devices, int ndev, int arch, const char *weigh
     SCHECK(rn_shard_load_dir(g, weights));
     SCHECK(rn_shard_finalize(g));
     printf("created model\n");
+    {   /* where every shard's host thread runs (stderr: stdout stays what the single-device run prints) */
+        int r;
+        for (r = 0; r < rn_shard_count(g); ++r) {
+            int dev = -1, node = -1;
+            char cpus[256];
+            if (rn_shard_placement(g, r, &dev, &node, cpus, sizeof(cpus)) == RN_OK)
+                fprintf(stderr, "rn_infer: shard %d on device %d, NUMA node %d, host thread on cpus [%s]\n", r, dev, node,
+                        cpus[0] ? cpus : "not bound");
+        }
+    }
     host = (float *)malloc(want * sizeof(float));
     idx = (uint64_t *)malloc(B * sizeof(uint64_t));
     f = fopen(input, "rb");

@@ -48,7 +48,7 @@ class Program:
         n_ops = int(g.integers(4, 14))
         for _ in range(n_ops):
             kind = str(g.choice(["conv", "conv", "conv", "bn", "relu", "add", "maxpool", "avgpool", "observe", "read",
-                                 "partial", "flush", "rewrite", "free", "newbn"]))
+                                 "partial", "flush", "rewrite", "free", "newbn", "slice_relu", "slice_conv"]))
             src = int(g.choice(live))
             Bs, C, Hs, Ws = self.shapes[src]
             if kind == "conv":
@@ -108,6 +108,18 @@ class Program:
                 live.append(dst)
             elif kind in ("observe", "read", "partial", "flush"):
                 self.steps.append((kind, src))
+            elif kind == "slice_relu" and Bs > 1:
+                # in place on ONE image of a batch: a pointer offset into what may be an NHWC-tagged buffer
+                self.steps.append(("slice_relu", src, int(g.integers(0, Bs))))
+            elif kind == "slice_conv" and Bs > 1 and C % 32 == 0:
+                b0 = int(g.integers(0, Bs))
+                dst = nxt
+                nxt += 1
+                self.shapes[dst] = (1, 32, Hs, Ws)
+                w = (g.standard_normal((32, C, 1, 1), dtype=np.float32) / np.sqrt(C)).astype(np.float32)
+                self.steps.append(("slice_conv", src, dst, len(self.params), b0))
+                self.params[len(self.params)] = [w]
+                live.append(dst)
             elif kind == "rewrite" and src != 0:
                 self.steps.append(("rewrite", src, len(self.params)))
                 self.params[len(self.params)] = [g.standard_normal(self.shapes[src], dtype=np.float32)]
@@ -181,6 +193,16 @@ class Program:
                 _, _, ho, wo = self.shapes[dst]
                 call(ctx, "rn_maxpool2d_forward" if kind == "maxpool" else "rn_avgpool2d_forward", tensor(src).data(),
                      tensor(dst).data(), k, s, p, ho, wo, Bs, C, Hs, Ws)
+            elif kind == "slice_relu":
+                _, src, b0 = st
+                Bs, C, Hs, Ws = self.shapes[src]
+                n = C * Hs * Ws
+                call(ctx, "rn_relu_forward", tensor(src).data() + 4 * n * b0, tensor(src).data() + 4 * n * b0, n)
+            elif kind == "slice_conv":
+                _, src, dst, pi, b0 = st
+                Bs, C, Hs, Ws = self.shapes[src]
+                call(ctx, "rn_conv2d_forward", tensor(src).data() + 4 * C * Hs * Ws * b0, tensor(dst).data(),
+                     param(pi)[0].data(), 1, 1, 0, Hs, Ws, 1, C, 32, Hs, Ws)
             elif kind == "observe":
                 ctx.observe(tensor(st[1]).data())
             elif kind == "flush":

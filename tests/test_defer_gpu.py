@@ -246,6 +246,40 @@ def test_observation_rules(dctx):
     assert np.abs(nhwc.numpy().transpose(0, 3, 1, 2) - want4).max() <= 1e-5
 
 
+def test_operands_that_are_slices_of_an_nhwc_tagged_buffer(dctx):
+    """A caller may hand a later op a PART of a tensor an earlier (fused, NHWC-writing) convolution produced: the
+    second image of the batch as a convolution input or a residual, an in-place ReLU on the first image only, an
+    output that covers part of a tagged buffer.  In the caller's NCHW arithmetic those are plain pointer offsets:
+    the tagged buffer gets its NCHW content back before such an op runs.  Against the literal route, bit for bit
+    (no batch-norm is folded here)."""
+    B, C, H, W = 3, 32, 8, 8
+    x, w = rnd((B, C, H, W), 21), rnd((C, C, 3, 3), 22, 0.06)
+    w1 = rnd((64, C, 1, 1), 23, 0.17)
+    img = C * H * W
+
+    def program(ctx):
+        dx, dw, dw1 = gpu(x), gpu(w), gpu(w1)
+        a = R.FloatTensor((B, C, H, W), R.Device.GPU)
+        b = R.FloatTensor((1, 64, H, W), R.Device.GPU)
+        c = R.FloatTensor((B, C, H, W), R.Device.GPU)
+        call(ctx, "rn_memset", c.data(), 0, B * img * 4)
+        call(ctx, "rn_conv2d_forward", dx.data(), a.data(), dw.data(), 3, 1, 1, H, W, B, C, C, H, W)       # a: NHWC-tagged
+        call(ctx, "rn_conv2d_forward", a.data() + img * 4, b.data(), dw1.data(), 1, 1, 0, H, W, 1, C, 64, H, W)  # image 1 of a
+        call(ctx, "rn_conv2d_forward", dx.data(), a.data(), dw.data(), 3, 1, 1, H, W, B, C, C, H, W)       # tagged again
+        call(ctx, "rn_relu_forward", a.data(), a.data(), img)                                               # image 0 only
+        call(ctx, "rn_conv2d_forward", dx.data(), a.data(), dw.data(), 3, 1, 1, H, W, B, C, C, H, W)
+        call(ctx, "rn_add_forward", c.data() + 2 * img * 4, a.data() + img * 4, c.data() + 2 * img * 4, img)  # slices of both
+        call(ctx, "rn_conv2d_forward", dx.data(), c.data(), dw.data(), 3, 1, 1, H, W, 2, C, C, H, W)       # covers 2 of c's 3 images
+        return [t.numpy() for t in (a, b, c)]
+
+    dctx.set_deferred(False)
+    want = program(dctx)
+    dctx.set_deferred(True)
+    got = program(dctx)
+    for g_, w_ in zip(got, want):
+        assert np.array_equal(g_, w_)
+
+
 def _build(tmp_path, name):
     exe = str(tmp_path / name)
     libdir = os.path.dirname(R._lib.LIB_PATH)
