@@ -14,8 +14,8 @@ file, moves to "cuda" and downloads pretrained weights.  Its three model
 definitions -- ``ResnetBlock``, ``make_layer``, ``Resnet152`` -- are pure
 torch.nn, so this script parses the file with ``ast``, compiles ONLY those three
 definitions (no other statement of the file is executed) and instantiates them
-on the CPU.  ResNet-50 is the same class with ``layer1..4`` rebuilt by the
-reference's own ``make_layer`` with 3/4/6/3 blocks.
+on the CPU.  ResNet-50 / ResNet-101 are the same class with ``layer1..4`` rebuilt by the
+reference's own ``make_layer`` with 3/4/6/3 and 3/4/23/3 blocks.
 
 Weights come from the build's deterministic generator
 (resnet_c_amd.weights.generate_state, seed 0) -- pretrained weights cannot be
@@ -129,7 +129,7 @@ def main():
         os.path.join(REF, "test_imgs", "ILSVRC2012_val_00004749.jpeg"))
     finch.tofile(os.path.join(HERE, "finch_224.bin"))
     rand2 = weights.generate_input(2, seed=7)
-    for arch in ("resnet50", "resnet152"):
+    for arch in ("resnet50", "resnet101", "resnet152"):
         m = build(ns, arch)
         y, rec = taps_of(m, torch.from_numpy(finch))
         np.save(os.path.join(HERE, f"{arch}_finch_logits.npy"), y.numpy())

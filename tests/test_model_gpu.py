@@ -562,18 +562,26 @@ def test_host_pipeline_matches_plain_forward_bit_exact(model50, finch):
     pipe.close()
 
 
-def test_resnet101_vs_oracle(finch):
-    """The third depth the model table knows ([3,4,23,3], the reference's layer lists are
-    main.cu:109-125 with other counts): no golden from the reference module is committed for
-    it, so it is checked against the oracle, which the RN-50/152 goldens pin."""
+def test_resnet101_vs_reference_golden_and_oracle(finch, golden_dir):
+    """The third depth the model table knows ([3,4,23,3]; the reference's layer lists are main.cu:109-125 with
+    other counts): against the golden logits of the reference's nn.Module classes rebuilt with those counts
+    (tests/golden/make_golden.py, round 4: both forward modes, the finch image and the random pair) and against
+    the oracle."""
     state = R.weights.generate_state("resnet101", seed=0)
     m = R.NativeModel("resnet101", state=state)
+    want = np.load(os.path.join(golden_dir, "resnet101_finch_logits.npy"))
+    want2 = np.load(os.path.join(golden_dir, "resnet101_rand2_logits.npy"))
+    info = json.load(open(os.path.join(golden_dir, "resnet101_taps.json")))
+    rand2 = R.weights.generate_input(2, seed=7)
     try:
         cpu = O.resnet_forward(state, finch, "resnet101")
         for fused in (False, True):
             got = m.forward(finch, fused=fused)
-            assert np.abs(got - cpu).max() <= TOL
-            assert np.array_equal(got.argmax(1), cpu.argmax(1))
+            assert np.abs(got - want).max() <= TOL and np.abs(got - cpu).max() <= TOL
+            assert R.ops.argmax(got)[0] == info["finch_top1"] == int(cpu.argmax(1)[0])
+            got2 = m.forward(rand2, fused=fused)
+            assert np.abs(got2 - want2).max() <= TOL
+            assert [int(v) for v in got2.argmax(1)] == info["rand2_top1"]
     finally:
         m.close()
 

@@ -25,7 +25,7 @@ def test_kat_reference_test_patterns(golden_dir):
     assert np.array_equal(O.relu(k["relu_x"]), k["relu_y"])
 
 
-@pytest.mark.parametrize("arch", ["resnet50", "resnet152"])
+@pytest.mark.parametrize("arch", ["resnet50", "resnet101", "resnet152"])
 def test_oracle_reproduces_reference_logits(arch, golden_dir, finch):
     """Golden logits were produced by the reference's nn.Module classes
     (tests/golden/make_golden.py).  Tolerance 1e-4 = the north star's; observed ~5e-6."""
