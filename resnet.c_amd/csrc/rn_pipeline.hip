@@ -242,16 +242,25 @@ int rn_pipeline_submit_n(rn_pipeline *p, const float *host_input_nchw, uint64_t 
                 std::vector<std::atomic<int>> landed(npieces);
                 for (auto &f : landed) f.store(0, std::memory_order_relaxed);
                 std::vector<std::thread> pool;
-                for (int t = 0; t < copiers; ++t)
-                    pool.emplace_back([&, t]() {
-                        for (size_t i = (size_t)t; i < npieces; i += (size_t)copiers) {
-                            copy_piece(i);
-                            landed[i].store(1, std::memory_order_release);
-                        }
-                    });
+                int started = 0;  // a thread that cannot be created leaves its pieces to this thread
+                try {
+                    for (int t = 0; t < copiers; ++t) {
+                        pool.emplace_back([&, t]() {
+                            for (size_t i = (size_t)t; i < npieces; i += (size_t)copiers) {
+                                copy_piece(i);
+                                landed[i].store(1, std::memory_order_release);
+                            }
+                        });
+                        ++started;
+                    }
+                } catch (...) {
+                }
                 hipError_t e = hipSuccess;
                 for (size_t i = 0; i < npieces && e == hipSuccess; ++i) {
-                    while (!landed[i].load(std::memory_order_acquire)) sched_yield();
+                    if ((int)(i % (size_t)copiers) >= started)
+                        copy_piece(i);
+                    else
+                        while (!landed[i].load(std::memory_order_acquire)) sched_yield();
                     e = upload_piece(i);
                 }
                 for (auto &th : pool) th.join();  // also on an error: the threads write into the slot's staging
