@@ -209,3 +209,18 @@ def test_committed_pmc_traffic_is_that_of_the_committed_kernel_sources():
         assert files, stem
         rec = json.load(open(files[-1]))
         assert rec["source_digest"] == L.source_digest(), f"{files[-1]}: re-run tools/evidence.sh pmc and commit profiles/"
+
+
+def test_bench_world_block_and_locality_degrade_gracefully():
+    """bench.py's per-rank records: without a device the locality query says nothing (no exception, no
+    binding); the world block carries every rank's own time and names the slowest."""
+    import bench
+
+    loc = bench.device_locality(0, bind=False)
+    assert loc == {} or {"pci", "numa_node", "local_cpus", "bound", "cpus_allowed"} <= set(loc)
+    ranks = [{"rank": 0, "ms_per_step": 17.0}, {"rank": 1, "ms_per_step": 19.5}, {"rank": 2, "ms_per_step": 16.9}]
+    wb = bench.world_block(ranks, 3, "nccl")
+    assert (wb["slowest_rank"], wb["slowest_rank_ms_per_step"], wb["fastest_rank_ms_per_step"]) == (1, 19.5, 16.9)
+    assert bench.world_block([{"rank": 0}], 1, None) == {"size": 1, "backend": None, "ranks": [{"rank": 0}]}
+    assert bench.gather_ranks({"rank": 0}, 1) == [{"rank": 0}]
+
