@@ -286,14 +286,22 @@ int run_conv(rn_ctx *ctx, size_t i, size_t *next)
     rn_epilogue ep;
     memset(&ep, 0, sizeof(ep));
     if (bn) RN_TRY(fold_for(ctx, *bn, &ep.scale, &ep.shift));
+    if (add && ((uintptr_t)(add->in == c.out ? add->in2 : add->in) & 15)) {
+        add = nullptr, relu = nullptr, j = i + 1 + (bn ? 1 : 0);  // the epilogue reads the residual in 16-byte rows
+    }
+    // Every rewrite of a buffer to NCHW (an operand tagged under ANOTHER shape: a view) comes first: it goes
+    // through scratch slot 3, which the transposed residual below lives in until the launch has read it.
+    // (the small-Cin form builds its padded image from the NCHW tensor: its input always goes back to NCHW)
+    if (c.Cin % 32 != 0 || !is_tagged_as(ds, c.in, c.B, c.Cin, c.H, c.W)) RN_TRY(materialise(ctx, c.in));
     if (add) {
         const float *r = add->in == c.out ? add->in2 : add->in;
-        if ((uintptr_t)r & 15) {  // the epilogue reads the residual in 16-byte rows
-            add = nullptr, relu = nullptr, j = i + 1 + (bn ? 1 : 0);
-        } else if (is_tagged_as(ds, r, c.B, c.Cout, c.ho, c.wo) || c.Cout == 1 || c.ho * c.wo == 1) {
+        if (!is_tagged_as(ds, r, c.B, c.Cout, c.ho, c.wo)) RN_TRY(materialise(ctx, r));
+    }
+    if (add) {
+        const float *r = add->in == c.out ? add->in2 : add->in;
+        if (is_tagged_as(ds, r, c.B, c.Cout, c.ho, c.wo) || c.Cout == 1 || c.ho * c.wo == 1) {
             ep.residual = r;
         } else {
-            RN_TRY(materialise(ctx, r));  // tagged with another shape (a view): its NCHW content is what counts
             void *rt = nullptr;
             RN_TRY(rn_scratch(ctx, 3, numel * sizeof(float), &rt));
             RN_TRY(rn_nchw_to_nhwc(ctx, r, (float *)rt, c.B, c.Cout, c.ho, c.wo));
@@ -307,7 +315,6 @@ int run_conv(rn_ctx *ctx, size_t i, size_t *next)
     if (c.Cin % 32 == 0) {
         const float *x = c.in;
         if (!is_tagged_as(ds, c.in, c.B, c.Cin, c.H, c.W) && c.H * c.W != 1) {
-            RN_TRY(materialise(ctx, c.in));
             void *xt = nullptr;
             RN_TRY(rn_scratch(ctx, 2, c.B * c.Cin * c.H * c.W * sizeof(float), &xt));
             RN_TRY(rn_nchw_to_nhwc(ctx, c.in, (float *)xt, c.B, c.Cin, c.H, c.W));
@@ -319,7 +326,6 @@ int run_conv(rn_ctx *ctx, size_t i, size_t *next)
         st = rn_conv2d_nhwc_forward(ctx, x, c.out, wp, c.k, c.s, c.p, c.ho, c.wo, c.B, c.Cin, c.Cout, c.H, c.W, epp);
     } else {
         // small Cin (the stem): NCHW image -> [B, H + 2p, W + 2p, Cin] with its zero border, exact-K panel
-        RN_TRY(materialise(ctx, c.in));
         const uint64_t Hp = c.H + 2 * c.p, Wp = c.W + 2 * c.p;
         void *xt = nullptr;
         RN_TRY(rn_scratch(ctx, 2, c.B * Hp * Wp * c.Cin * sizeof(float), &xt));

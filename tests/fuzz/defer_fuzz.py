@@ -48,7 +48,8 @@ class Program:
         n_ops = int(g.integers(4, 14))
         for _ in range(n_ops):
             kind = str(g.choice(["conv", "conv", "conv", "bn", "relu", "add", "maxpool", "avgpool", "observe", "read",
-                                 "partial", "flush", "rewrite", "free", "newbn", "slice_relu", "slice_conv"]))
+                                 "partial", "flush", "rewrite", "free", "newbn", "slice_relu", "slice_conv", "view_conv",
+                                 "view_bn"]))
             src = int(g.choice(live))
             Bs, C, Hs, Ws = self.shapes[src]
             if kind == "conv":
@@ -108,6 +109,20 @@ class Program:
                 live.append(dst)
             elif kind in ("observe", "read", "partial", "flush"):
                 self.steps.append((kind, src))
+            elif kind == "view_conv" and C % 64 == 0:
+                # the same buffer under another shape (Tensor::view): [B, C, H, W] read as [B, C/2, H, 2W]
+                dst = nxt
+                nxt += 1
+                self.shapes[dst] = (Bs, 32, Hs, 2 * Ws)
+                w = (g.standard_normal((32, C // 2, 1, 1), dtype=np.float32) / np.sqrt(C // 2)).astype(np.float32)
+                self.steps.append(("view_conv", src, dst, len(self.params)))
+                self.params[len(self.params)] = [w]
+                live.append(dst)
+            elif kind == "view_bn" and C % 2 == 0:
+                self.steps.append(("view_bn", src, len(self.params)))   # in place, as [B, C/2, H, 2W]
+                C2 = C // 2
+                self.params[len(self.params)] = [g.random(C2, dtype=np.float32) + 0.5, g.standard_normal(C2, dtype=np.float32) * 0.1,
+                                                 g.standard_normal(C2, dtype=np.float32) * 0.1, g.random(C2, dtype=np.float32) + 0.5]
             elif kind == "slice_relu" and Bs > 1:
                 # in place on ONE image of a batch: a pointer offset into what may be an NHWC-tagged buffer
                 self.steps.append(("slice_relu", src, int(g.integers(0, Bs))))
@@ -193,6 +208,16 @@ class Program:
                 _, _, ho, wo = self.shapes[dst]
                 call(ctx, "rn_maxpool2d_forward" if kind == "maxpool" else "rn_avgpool2d_forward", tensor(src).data(),
                      tensor(dst).data(), k, s, p, ho, wo, Bs, C, Hs, Ws)
+            elif kind == "view_conv":
+                _, src, dst, pi = st
+                Bs, C, Hs, Ws = self.shapes[src]
+                call(ctx, "rn_conv2d_forward", tensor(src).data(), tensor(dst).data(), param(pi)[0].data(), 1, 1, 0,
+                     Hs, 2 * Ws, Bs, C // 2, 32, Hs, 2 * Ws)
+            elif kind == "view_bn":
+                _, src, pi = st
+                Bs, C, Hs, Ws = self.shapes[src]
+                call(ctx, "rn_batchnorm2d_forward", tensor(src).data(), tensor(src).data(), *(q.data() for q in param(pi)),
+                     Bs, C // 2, 2 * Hs * Ws)
             elif kind == "slice_relu":
                 _, src, b0 = st
                 Bs, C, Hs, Ws = self.shapes[src]

@@ -280,6 +280,38 @@ def test_operands_that_are_slices_of_an_nhwc_tagged_buffer(dctx):
         assert np.array_equal(g_, w_)
 
 
+def test_operands_tagged_under_another_shape(dctx):
+    """The same device buffer seen under two shapes (Tensor::view shares storage): a convolution output
+    [B, 64, 8, 8] -- NHWC-tagged -- is handed on as [B, 32, 8, 16], as the INPUT of the next convolution and as
+    the RESIDUAL of another.  NCHW arithmetic on the caller's side: the buffer goes back to NCHW before either
+    use, and both rewrites happen before the launch's own scratch (the transposed residual) is in use."""
+    B = 2
+    x, w = rnd((B, 32, 8, 8), 31), rnd((64, 32, 3, 3), 32, 0.06)
+    w2 = rnd((32, 32, 1, 1), 33, 0.17)
+    other = rnd((B, 32, 8, 16), 34)
+
+    def program(ctx):
+        dx, dw, dw2, dother = gpu(x), gpu(w), gpu(w2), gpu(other)
+        a = R.FloatTensor((B, 64, 8, 8), R.Device.GPU)        # also read as [B, 32, 8, 16]
+        r = R.FloatTensor((B, 64, 8, 8), R.Device.GPU)        # likewise: the residual
+        y = R.FloatTensor((B, 32, 8, 16), R.Device.GPU)
+        n = B * 32 * 8 * 16
+        call(ctx, "rn_conv2d_forward", dx.data(), a.data(), dw.data(), 3, 1, 1, 8, 8, B, 32, 64, 8, 8)    # a tagged [B,64,8,8]
+        call(ctx, "rn_conv2d_forward", dx.data(), r.data(), dw.data(), 3, 1, 1, 8, 8, B, 32, 64, 8, 8)    # r tagged [B,64,8,8]
+        call(ctx, "rn_relu_forward", r.data(), r.data(), n)
+        call(ctx, "rn_conv2d_forward", a.data(), y.data(), dw2.data(), 1, 1, 0, 8, 16, B, 32, 32, 8, 16)  # a as [B,32,8,16]
+        call(ctx, "rn_add_forward", y.data(), r.data(), y.data(), n)                                      # r as [B,32,8,16]
+        call(ctx, "rn_relu_forward", y.data(), y.data(), n)
+        return [t.numpy() for t in (a, r)] + [y.numpy()]
+
+    dctx.set_deferred(False)
+    want = program(dctx)
+    dctx.set_deferred(True)
+    got = program(dctx)
+    for g_, w_ in zip(got, want):
+        assert np.array_equal(g_, w_)
+
+
 def _build(tmp_path, name):
     exe = str(tmp_path / name)
     libdir = os.path.dirname(R._lib.LIB_PATH)
