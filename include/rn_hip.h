@@ -109,7 +109,11 @@ RN_API int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on);
  * network), and a buffer gets its NCHW content back only when it is observed (a whole-tensor
  * rn_memcpy_d2h transposes on its way out; rn_observe, partial reads, device-to-device copies and
  * entry points outside the seven rewrite the buffer in place first).  Every buffer named as an output
- * holds its value once the list has run: only in-place chains are folded, nothing is skipped.
+ * holds its value once the list has run: only in-place chains are folded, nothing is skipped.  Where
+ * such a group is conv3 + bn + add + ReLU of a 64-channel bottleneck block and the next recorded group
+ * is conv1 + bn + ReLU of the following block on that output, both run as one launch
+ * (rn_conv_chain_forward_dt: the block output is written on its way to conv1; the same bits as the two
+ * launches; RN_DEFER_CHAINS=0 in the environment keeps them apart).
  * Contract for the caller: device memory it handed to the seven ops is read and written by other
  * means (own kernels, hipMemcpy) only after rn_observe(ctx, ptr) -- the C++ veneer's Tensor::data()
  * does that; weights and batch-norm parameters are cached in packed / folded form per buffer and the
@@ -163,6 +167,12 @@ RN_API int rn_ctx_set_stem_items(rn_ctx *ctx, int items);
  * major (an XCD reads its input rows once and streams the whole weight panel); 2 / 4 / 8: forced (also
  * RN_XCD_NGROUPS in the environment at context creation).  Changes which block computes a tile, no bit. */
 RN_API int rn_ctx_set_xcd_groups(rn_ctx *ctx, int groups);
+/* rn_conv2d_forward on NCHW tensors (RN_LAYOUT_NCHW, not deferred), kernel_size > 1: 0 = transpose the input into
+ * scratch and run the NHWC contraction (its epilogue writes NCHW); 2 = gather the taps from the channel planes
+ * (rn_conv_nchw.hip) wherever the shape is eligible (in_channels % 32 == 0, kernel_size <= 7); 1 (default) = gather
+ * on planes of 2048 pixels or more, where it measures faster (tools/nchw_bench.py).  Also RN_NCHW_TAPS in the
+ * environment at context creation.  Changes the route, no bit. */
+RN_API int rn_ctx_set_nchw_taps(rn_ctx *ctx, int mode);
 /* Diagnostics: device buffer of 16 x uint64 per block that the contraction kernel fills with
  * wall-clock and shader-clock stamps of its phases (tools/conv_stamps.py); NULL (default) = off. */
 RN_API int rn_ctx_set_debug_stamps(rn_ctx *ctx, void *dev_buffer);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "rn_ctx_set_split_k": (c_int, [c_void_p, c_int]),
     "rn_ctx_set_stem_items": (c_int, [c_void_p, c_int]),
     "rn_ctx_set_xcd_groups": (c_int, [c_void_p, c_int]),
+    "rn_ctx_set_nchw_taps": (c_int, [c_void_p, c_int]),
     "rn_ctx_set_debug_stamps": (c_int, [c_void_p, c_void_p]),
     "rn_ctx_stream": (c_void_p, [c_void_p]),
     "rn_ctx_device": (c_int, [c_void_p]),

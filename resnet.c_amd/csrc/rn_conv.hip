@@ -1374,12 +1374,13 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
                              ctx->layout == RN_LAYOUT_NHWC, 0, nullptr,
                              "rn_conv2d_forward(direct)");
     }
-    // 1x1 / stride 1 on NCHW tensors: NCHW is the MFMA's own layout with the operands swapped
-    // (rn_conv_nchw.hip) -- no transpose of the input, no packing of the weight, the same bits
-    if (ctx->layout == RN_LAYOUT_NCHW &&
-        rn_conv1x1_nchw_eligible(kernel_size, stride, padding, B, in_channels, out_channels, H, W) &&
-        (reinterpret_cast<uintptr_t>(weight) & 15) == 0 && h_out == (H - 1) / stride + 1 && w_out == (W - 1) / stride + 1)
-        return rn_conv1x1_nchw_launch(ctx, inp, out, weight, stride, B, in_channels, out_channels, H, W);
+    // NCHW tensors: NCHW is the MFMA's own layout with the operands swapped (rn_conv_nchw.hip) -- no transpose of
+    // the input, the same bits.  1x1: the OIHW weight as it is, no packing either
+    const bool native = ctx->layout == RN_LAYOUT_NCHW && h_out == (H + 2 * padding - kernel_size) / stride + 1 &&
+                        w_out == (W + 2 * padding - kernel_size) / stride + 1 &&
+                        rn_conv_nchw_eligible(kernel_size, stride, padding, B, in_channels, out_channels, H, W);
+    if (native && kernel_size == 1 && padding == 0 && (reinterpret_cast<uintptr_t>(weight) & 15) == 0)
+        return rn_conv_nchw_launch(ctx, inp, out, weight, 1, stride, 0, B, in_channels, out_channels, H, W);
     // K-major panel of the OIHW weight: packed per call into scratch, or -- with the context's
     // weight cache on -- once per (weight buffer, shape) and kept until that buffer is freed or
     // written through the rn_* calls
@@ -1402,7 +1403,14 @@ int rn_conv2d_forward(rn_ctx *ctx, const float *inp, float *out, const float *we
                            padding, h_out, w_out, B, in_channels, out_channels, H, W, nullptr,
                            "rn_conv2d_forward(nhwc)");
     }
-    // NCHW caller: transpose in, contract; the contraction's epilogue writes NCHW itself
+    // k x k on NCHW tensors: the taps gathered from the channel planes, the packed panel as the MFMA rows.
+    // Measured at B = 256 (tools/nchw_bench.py, RN_NCHW_TAPS=2 against 0): the gathering K loop is 15-25 % slower
+    // per tile than the NHWC one, the transpose it saves costs 70 us on a 56x56 tensor and 10-25 us on the
+    // 14x14 / 7x7 ones -- it pays on the large planes only (rn_ctx_set_nchw_taps: 1, the default)
+    if (native && (ctx->nchw_taps >= 2 || (ctx->nchw_taps == 1 && H * W >= 2048)))
+        return rn_conv_nchw_launch(ctx, inp, out, (const float *)wp, kernel_size, stride, padding, B, in_channels,
+                                   out_channels, H, W);
+    // anything else on NCHW tensors: transpose in, contract; the contraction's epilogue writes NCHW itself
     const uint64_t cs = rn_conv2d_input_channels(in_channels);
     void *xin = nullptr;
     RN_TRY(rn_scratch(ctx, 2, B * H * W * cs * sizeof(float), &xin));

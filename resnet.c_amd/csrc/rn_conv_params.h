@@ -123,12 +123,12 @@ void rn_conv_wide_launch(rn_ctx *ctx, rn_gemm::GemmParams &p, int which, bool du
 bool rn_conv_strip_eligible(const rn_gemm::GemmParams &p);
 void rn_conv_strip_launch(rn_ctx *ctx, const rn_gemm::GemmParams &p);
 
-// fp32 1x1 / padding 0 convolution on NCHW tensors with the OIHW weight as it is (rn_conv_nchw.hip):
-// the literal drop-in route's rn_conv2d_forward without the input transpose.  Same bits as the
-// NHWC contraction.
-bool rn_conv1x1_nchw_eligible(uint64_t kernel_size, uint64_t stride, uint64_t padding, uint64_t B,
-                              uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W);
-int rn_conv1x1_nchw_launch(rn_ctx *ctx, const float *inp, float *out, const float *weight, uint64_t stride,
-                           uint64_t B, uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W);
+// fp32 convolution on NCHW tensors without the input transpose (rn_conv_nchw.hip): the literal drop-in route's
+// rn_conv2d_forward.  weight = [Cout][kh][kw][Cin]: the OIHW buffer as it is for kernel_size 1, the packed panel
+// otherwise.  Same bits as the NHWC contraction.
+bool rn_conv_nchw_eligible(uint64_t kernel_size, uint64_t stride, uint64_t padding, uint64_t B, uint64_t Cin,
+                           uint64_t Cout, uint64_t H, uint64_t W);
+int rn_conv_nchw_launch(rn_ctx *ctx, const float *inp, float *out, const float *weight, uint64_t kernel_size,
+                        uint64_t stride, uint64_t padding, uint64_t B, uint64_t Cin, uint64_t Cout, uint64_t H, uint64_t W);
 
 #endif

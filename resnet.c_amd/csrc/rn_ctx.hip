@@ -209,6 +209,11 @@ int rn_ctx_create(rn_ctx **out, int device, void *hip_stream)
         const int g = atoi(xg);
         if (g == 1 || g == 2 || g == 4 || g == 8) ctx->xcd_groups = g;
     }
+    ctx->nchw_taps = 1;
+    if (const char *nt = getenv("RN_NCHW_TAPS")) {  // A/B runs of the literal route (tools/nchw_bench.py)
+        const int v = atoi(nt);
+        if (v >= 0 && v <= 2) ctx->nchw_taps = v;
+    }
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
         ctx->own_stream = false;
@@ -293,6 +298,14 @@ int rn_ctx_set_xcd_groups(rn_ctx *ctx, int groups)
     if (groups != 0 && groups != 1 && groups != 2 && groups != 4 && groups != 8)
         return rn_set_error(ctx, RN_ERR_INVALID, "xcd groups %d: 0 (chosen per launch), 1, 2, 4 or 8", groups);
     ctx->xcd_groups = groups;
+    return RN_OK;
+}
+
+int rn_ctx_set_nchw_taps(rn_ctx *ctx, int mode)
+{
+    if (!ctx) return RN_ERR_INVALID;
+    if (mode < 0 || mode > 2) return rn_set_error(ctx, RN_ERR_INVALID, "nchw taps mode %d: 0 (never), 1 (large planes) or 2 (always)", mode);
+    ctx->nchw_taps = mode;
     return RN_OK;
 }
 

@@ -78,6 +78,8 @@ struct rn_defer_state {
     std::vector<Fold> folds;
     std::vector<ExactPack> exact;
     uint64_t fused_launches = 0, literal_launches = 0, transposes = 0;
+    // conv3 of a 64-channel block + conv1 of the next as one launch (rn_chain.hip); RN_DEFER_CHAINS=0: A/B runs
+    bool chains = !(getenv("RN_DEFER_CHAINS") && atoi(getenv("RN_DEFER_CHAINS")) == 0);
 };
 
 namespace {
@@ -254,6 +256,57 @@ bool fusable_conv(const Op &c)
            c.B * (c.H + 2 * c.p) * (c.W + 2 * c.p) * c.Cin < lim;
 }
 
+// c = conv3 (1x1, 64 -> 256) with bn + add + ReLU folded, ops[j] = the convolution behind that group.  When that is
+// conv1 of the next block on c's output (1x1, 256 -> 64 | 128, bn and ReLU in place behind it) and every tensor is
+// already NHWC, both groups run as ONE launch (rn_conv_chain_forward_dt: the block output is written on its way
+// through LDS, so the caller's tensor holds its value as ever; the same bits as the two launches).  *done = taken.
+int try_chain(rn_ctx *ctx, const Op &c, const Op &bn, const float *r, size_t j, size_t *next, bool *done)
+{
+    rn_defer_state *ds = ctx->ds;
+    const size_t n = ds->ops.size();
+    *done = false;
+    if (!ds->chains || j >= n || ds->ops[j].kind != K_CONV) return RN_OK;
+    if (!(c.k == 1 && c.s == 1 && c.p == 0 && c.Cin == 64 && c.Cout == 256 && c.ho == c.H && c.wo == c.W)) return RN_OK;
+    const Op c2 = ds->ops[j];
+    if (!(c2.in == c.out && c2.k == 1 && c2.s == 1 && c2.p == 0 && c2.Cin == 256 && (c2.Cout == 64 || c2.Cout == 128) &&
+          c2.B == c.B && c2.H == c.H && c2.W == c.W && c2.ho == c.H && c2.wo == c.W && fusable_conv(c2)))
+        return RN_OK;
+    const uint64_t rows = c.B * c.H * c.W, f = sizeof(float);
+    if (rows * 256 * f >= (1ull << 31)) return RN_OK;
+    size_t j2 = j + 1;
+    const Op *bn2 = nullptr, *relu2 = nullptr;
+    if (j2 < n && ds->ops[j2].kind == K_BN && ds->ops[j2].in == c2.out && ds->ops[j2].out == c2.out &&
+        ds->ops[j2].Cout == c2.Cout && ds->ops[j2].B == c2.B && ds->ops[j2].N == c2.ho * c2.wo)
+        bn2 = &ds->ops[j2++];
+    if (j2 < n && ds->ops[j2].kind == K_RELU && ds->ops[j2].in == c2.out && ds->ops[j2].out == c2.out &&
+        ds->ops[j2].N == rows * c2.Cout)
+        relu2 = &ds->ops[j2++];
+    if (!relu2) return RN_OK;
+    // the kernel reads its inputs a step ahead of the rows it writes: no output on top of an input or of the other
+    const void *bufs[4] = {c.in, r, c.out, c2.out};
+    const uint64_t sizes[4] = {rows * 64 * f, rows * 256 * f, rows * 256 * f, rows * c2.Cout * f};
+    for (int a = 0; a < 4; ++a)
+        for (int b = a + 1; b < 4; ++b)
+            if ((a >= 2 || b >= 2) && overlaps(bufs[a], sizes[a], bufs[b], sizes[b])) return RN_OK;
+    RN_TRY(settle_op(ctx, c2));
+    if (bn2) RN_TRY(settle_op(ctx, *bn2));
+    RN_TRY(settle_op(ctx, *relu2));
+    if (!is_tagged_as(ds, c.in, c.B, 64, c.H, c.W) || !is_tagged_as(ds, r, c.B, 256, c.H, c.W)) return RN_OK;
+    const float *sc3 = nullptr, *sh3 = nullptr, *sc1 = nullptr, *sh1 = nullptr, *w3 = nullptr, *w1 = nullptr;
+    RN_TRY(fold_for(ctx, bn, &sc3, &sh3));
+    if (bn2) RN_TRY(fold_for(ctx, *bn2, &sc1, &sh1));
+    RN_TRY(packed_for(ctx, c, &w3));
+    RN_TRY(packed_for(ctx, c2, &w1));
+    RN_TRY(rn_conv_chain_forward_dt(ctx, RN_DTYPE_F32, c.in, r, c.out, w3, sc3, sh3, c2.out, w1, sc1, sh1, rows, 64, 256,
+                                    c2.Cout));
+    set_tag(ds, c.out, c.B, 256, c.H, c.W);
+    set_tag(ds, c2.out, c.B, c2.Cout, c.H, c.W);
+    ++ds->fused_launches;
+    *next = j2;
+    *done = true;
+    return RN_OK;
+}
+
 // ops[i] is a convolution: fold the in-place chain behind it into its epilogue; *next = first op not consumed
 int run_conv(rn_ctx *ctx, size_t i, size_t *next)
 {
@@ -296,6 +349,11 @@ int run_conv(rn_ctx *ctx, size_t i, size_t *next)
     if (add) {
         const float *r = add->in == c.out ? add->in2 : add->in;
         if (!is_tagged_as(ds, r, c.B, c.Cout, c.ho, c.wo)) RN_TRY(materialise(ctx, r));
+    }
+    if (bn && add && relu) {
+        bool done = false;
+        RN_TRY(try_chain(ctx, c, *bn, add->in == c.out ? add->in2 : add->in, j, next, &done));
+        if (done) return RN_OK;
     }
     if (add) {
         const float *r = add->in == c.out ? add->in2 : add->in;

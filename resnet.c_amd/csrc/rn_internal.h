@@ -25,6 +25,7 @@ struct rn_ctx {
     int graphs_live;  // captured forwards that hold pointers into the scratch and the arenas
     int split_k;    // 0 = never split the K loop; n = up to n partial sums per output (latency mode)
     int stem_items; // fused stem: items (four stem rows) a block walks; 0 = chosen per launch
+    int nchw_taps;  // k x k convolutions on NCHW tensors without the input transpose: 0 never, 1 large planes, 2 always
     int xcd_groups; // N-tile groups the contraction's tiles are dealt to the XCDs in; 0 = chosen per launch
     void *debug_stamps;  // diagnostic phase stamps of the contraction kernel, normally null
     // scratch grown on demand (never inside a graph capture; callers that capture

@@ -90,6 +90,12 @@ class Context:
         of N tiles (rn_ctx_set_xcd_groups).  Changes which block computes a tile, never a bit."""
         L.check(L.lib().rn_ctx_set_xcd_groups(self.handle, int(groups)), "rn_ctx_set_xcd_groups", self.handle)
 
+    def set_nchw_taps(self, mode: int) -> None:
+        """k x k convolutions of rn_conv2d_forward on NCHW tensors: 0 = transpose the input and contract in NHWC,
+        2 = gather the taps from the channel planes, 1 = gather on large planes only (rn_ctx_set_nchw_taps).  Changes
+        the route, never a bit."""
+        L.check(L.lib().rn_ctx_set_nchw_taps(self.handle, int(mode)), "rn_ctx_set_nchw_taps", self.handle)
+
     def set_weight_cache(self, on: bool) -> None:
         """rn_conv2d_forward (OIHW weights) packs each weight buffer once instead of per call."""
         L.check(L.lib().rn_ctx_set_weight_cache(self.handle, int(on)), "rn_ctx_set_weight_cache")

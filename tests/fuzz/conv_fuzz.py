@@ -58,7 +58,10 @@ def main():
             for c in cands:
                 lib.rn_ctx_set_conv_tile(ctx.handle, c)
                 if kind in ("nchw", "nhwc"):
+                    # (NCHW, k x k: the gathering kernel, the transposing route or the default choice between them)
+                    ctx.set_nchw_taps(int(g.integers(0, 3)))
                     got = ops.conv2d(x, w, stride, pad, kind)
+                    ctx.set_nchw_taps(1)
                     ref, tol = want, 3e-7 * np.sqrt(K) * scale + 1e-6
                 elif kind == "fused":
                     sc = g.random(Cout, dtype=np.float32) + 0.5

@@ -49,7 +49,7 @@ class Program:
         for _ in range(n_ops):
             kind = str(g.choice(["conv", "conv", "conv", "bn", "relu", "add", "maxpool", "avgpool", "observe", "read",
                                  "partial", "flush", "rewrite", "free", "newbn", "slice_relu", "slice_conv", "view_conv",
-                                 "view_bn"]))
+                                 "view_bn", "boundary"]))
             src = int(g.choice(live))
             Bs, C, Hs, Ws = self.shapes[src]
             if kind == "conv":
@@ -81,6 +81,32 @@ class Program:
                         if same:
                             r = int(g.choice(same))
                             self.steps.append(("add", dst, r, dst) if g.random() < 0.8 else ("add", r, dst, dst))
+            elif kind == "boundary" and C == 64:
+                # a block boundary of layer1 (main.cu:131-164): conv3 -> bn -> add -> relu of a 64-channel block, conv1
+                # -> bn -> relu of the next on its output -- one launch when nothing comes between (rn_chain.hip);
+                # sometimes something does
+                def conv1x1(a, Cin_, Cout_):
+                    nonlocal nxt
+                    d = nxt
+                    nxt += 1
+                    self.shapes[d] = (Bs, Cout_, Hs, Ws)
+                    w = (g.standard_normal((Cout_, Cin_, 1, 1), dtype=np.float32) / np.sqrt(Cin_)).astype(np.float32)
+                    self.steps.append(("conv", a, d, len(self.params), 1, 1, 0))
+                    self.params[len(self.params)] = [w]
+                    live.append(d)
+                    return d
+                r = conv1x1(src, 64, 256)
+                y = conv1x1(src, 64, 256)
+                self._bn(y, y)
+                self.steps.append(("add", y, r, y) if g.random() < 0.8 else ("add", r, y, y))
+                self.steps.append(("relu", y, y))
+                if g.random() < 0.3:
+                    self.steps.append((str(g.choice(["observe", "read", "partial", "flush"])), int(g.choice([y, r, src]))))
+                t1 = conv1x1(y, 256, int(g.choice([64, 128])))
+                if g.random() < 0.8:
+                    self._bn(t1, t1)
+                if g.random() < 0.9:
+                    self.steps.append(("relu", t1, t1))
             elif kind == "bn":
                 dst = src if g.random() < 0.7 else self._new_like(src, live)
                 nxt = max(nxt, dst + 1)

@@ -47,7 +47,8 @@ def call(ctx, name, *args):
 
 def test_whole_network_deferred_matches_goldens_and_the_literal_route(state50, finch, golden_dir, dctx):
     """createResnet / resnetForward (the reference driver object for object, one C-ABI call per reference
-    op on NCHW tensors) on a deferred context: 53 fused launches, no literal batch-norm / ReLU / add pass,
+    op on NCHW tensors) on a deferred context: 51 fused launches for the 53 convolutions (conv3 of layer1's first
+    two blocks runs in one launch with conv1 of the block behind it), no literal batch-norm / ReLU / add pass,
     one layout pass for the input; logits within the bar of the reference module's goldens and within the
     fused epilogue's distance of the literal route; intermediate tensors come back as NCHW when observed."""
     x = np.concatenate([finch, R.weights.generate_input(2, seed=5)])
@@ -64,7 +65,8 @@ def test_whole_network_deferred_matches_goldens_and_the_literal_route(state50, f
     got = out.numpy()                                           # observed: the list runs
     s1 = dctx.deferred_stats()
     assert s1["pending_ops"] == 0
-    assert s1["fused_launches"] - s0["fused_launches"] == 53    # every convolution with its chain folded in
+    # every convolution with its in-place ops folded in; layer1: conv3 of blocks 0 and 1 + conv1 of the next, one launch
+    assert s1["fused_launches"] - s0["fused_launches"] == 51
     assert s1["literal_launches"] - s0["literal_launches"] == 3  # max-pool, avg-pool, fc
     assert s1["transposes"] - s0["transposes"] == 1             # the NCHW input image -> padded NHWC
     want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
@@ -126,6 +128,68 @@ def test_fused_chain_against_the_oracle(case, dctx):
         assert np.abs(got2 - want2).max() <= tol + 3e-6 * np.sqrt(Cout) * float(np.abs(res2).max())
         # layout passes: dres -> NHWC for the 1x1, x -> NHWC for the chain, out -> NCHW for the read; none for r2
         assert dctx.deferred_stats()["transposes"] - t0 == (3 if H * W > 1 else 1)
+
+
+@pytest.mark.parametrize("next_mid", [64, 128])
+def test_conv3_of_a_block_and_conv1_of_the_next_run_as_one_launch(next_mid, dctx):
+    """layerForward's block boundary (main.cu:131-164): conv3 -> bn3 -> add -> relu of a 64-channel block, then
+    conv1 -> bn1 -> relu of the next block on that output.  Recorded on a deferred context with NHWC-tagged inputs,
+    the seven calls run as ONE launch (rn_conv_chain_forward_dt) that writes both tensors; both against the oracle,
+    and bit for bit what the two fused launches give (the same calls with an op in between that breaks the
+    pattern: a ReLU of an unrelated buffer)."""
+    B, H, W = 3, 10, 9
+    g = 900 + next_mid
+    x0, x1 = rnd((B, 64, H, W), g), rnd((B, 64, H, W), g + 1)
+    wa, wb = rnd((64, 64, 1, 1), g + 2, 0.125), rnd((256, 64, 1, 1), g + 3, 0.125)
+    w3, w1 = rnd((256, 64, 1, 1), g + 4, 0.125), rnd((next_mid, 256, 1, 1), g + 5, 1 / 16)
+    p3, p1 = bn_params(256, g + 6), bn_params(next_mid, g + 7)
+    t2_ = O.conv2d(x0, wa, 1, 0)                      # both inputs of the chain come out of deferred convolutions:
+    r_ = O.conv2d(x1, wb, 1, 0)                       # NHWC in their buffers when the chain runs
+    y_ = O.relu_(O.add_(O.batchnorm2d_(O.conv2d(t2_, w3, 1, 0), *p3), r_))
+    t1_ = O.relu_(O.batchnorm2d_(O.conv2d(y_, w1, 1, 0), *p1))
+    D = {k: gpu(v) for k, v in dict(x0=x0, x1=x1, wa=wa, wb=wb, w3=w3, w1=w1).items()}
+    P3, P1 = [gpu(v) for v in p3], [gpu(v) for v in p1]
+    t2, r = R.FloatTensor((B, 64, H, W), R.Device.GPU), R.FloatTensor((B, 256, H, W), R.Device.GPU)
+    y, t1 = R.FloatTensor((B, 256, H, W), R.Device.GPU), R.FloatTensor((B, next_mid, H, W), R.Device.GPU)
+    other = gpu(rnd((8,), g + 8))
+    hw = H * W
+
+    def program(split):
+        call(dctx, "rn_conv2d_forward", D["x0"].data(), t2.data(), D["wa"].data(), 1, 1, 0, H, W, B, 64, 64, H, W)
+        call(dctx, "rn_conv2d_forward", D["x1"].data(), r.data(), D["wb"].data(), 1, 1, 0, H, W, B, 64, 256, H, W)
+        call(dctx, "rn_conv2d_forward", t2.data(), y.data(), D["w3"].data(), 1, 1, 0, H, W, B, 64, 256, H, W)
+        call(dctx, "rn_batchnorm2d_forward", y.data(), y.data(), *(t.data() for t in P3), B, 256, hw)
+        call(dctx, "rn_add_forward", y.data(), r.data(), y.data(), B * 256 * hw)
+        call(dctx, "rn_relu_forward", y.data(), y.data(), B * 256 * hw)
+        if split:
+            call(dctx, "rn_relu_forward", other.data(), other.data(), 8)
+        call(dctx, "rn_conv2d_forward", y.data(), t1.data(), D["w1"].data(), 1, 1, 0, H, W, B, 256, next_mid, H, W)
+        call(dctx, "rn_batchnorm2d_forward", t1.data(), t1.data(), *(t.data() for t in P1), B, next_mid, hw)
+        call(dctx, "rn_relu_forward", t1.data(), t1.data(), B * next_mid * hw)
+        s0 = dctx.deferred_stats()
+        dctx.flush()
+        s1 = dctx.deferred_stats()
+        return s1["fused_launches"] - s0["fused_launches"], y.numpy().copy(), t1.numpy().copy()
+
+    n_two, y_two, t1_two = program(True)
+    n_one, y_one, t1_one = program(False)
+    assert (n_two, n_one) == (4, 3)
+    assert np.array_equal(y_one, y_two) and np.array_equal(t1_one, t1_two)
+    assert np.abs(y_one - y_) .max() <= 3e-6 * 8 * float(np.abs(y_).max()) + 1e-5
+    assert np.abs(t1_one - t1_).max() <= 3e-6 * 16 * float(np.abs(t1_).max()) + 2e-5
+    # a residual that is a plain NCHW tensor (not produced on this context): the two-launch form, same values
+    r_plain = gpu(r_)
+    call(dctx, "rn_conv2d_forward", t2.data(), y.data(), D["w3"].data(), 1, 1, 0, H, W, B, 64, 256, H, W)
+    call(dctx, "rn_batchnorm2d_forward", y.data(), y.data(), *(t.data() for t in P3), B, 256, hw)
+    call(dctx, "rn_add_forward", y.data(), r_plain.data(), y.data(), B * 256 * hw)
+    call(dctx, "rn_relu_forward", y.data(), y.data(), B * 256 * hw)
+    call(dctx, "rn_conv2d_forward", y.data(), t1.data(), D["w1"].data(), 1, 1, 0, H, W, B, 256, next_mid, H, W)
+    call(dctx, "rn_batchnorm2d_forward", t1.data(), t1.data(), *(t.data() for t in P1), B, next_mid, hw)
+    call(dctx, "rn_relu_forward", t1.data(), t1.data(), B * next_mid * hw)
+    s0 = dctx.deferred_stats()
+    dctx.flush()
+    assert dctx.deferred_stats()["fused_launches"] - s0["fused_launches"] == 2
+    assert np.abs(t1.numpy() - t1_).max() <= 3e-6 * 16 * float(np.abs(t1_).max()) + 2e-5
 
 
 def test_sequences_that_do_not_fold_run_literally_in_call_order(dctx):

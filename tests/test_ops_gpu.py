@@ -649,8 +649,9 @@ def test_one_thread_two_contexts_interleaved():
                                   (3, 96, 64, 5, 1, 1, 1, 0)])       # one-pixel-wide planes
 def test_nchw_route_writes_the_nhwc_routes_bits(case):
     """rn_conv2d_forward on NCHW tensors: a 1x1 / padding-0 convolution runs on the NCHW-native
-    kernel (rn_conv_nchw.hip: weights = MFMA rows, pixels = columns, no transpose, no packing);
-    anything else transposes its input and lets the contraction's epilogue write NCHW itself
+    kernel (rn_conv_nchw.hip: weights = MFMA rows, pixels = columns, no transpose, no packing), a
+    k x k one on its gathering form (large planes, or rn_ctx_set_nchw_taps(2)) or on the route that
+    transposes its input and lets the contraction's epilogue write NCHW itself
     (GemmParams::out_nchw).  Same products and the same summation order as the NHWC call -- also
     where the NHWC launch cuts its tail tiles into K chunks and a finishing kernel adds them -- so
     the two layouts must agree bit for bit, and with the oracle."""
@@ -660,6 +661,12 @@ def test_nchw_route_writes_the_nhwc_routes_bits(case):
     if Cin >= 4:   # (an NHWC call with fewer than four channels takes the direct kernel: another order)
         assert np.array_equal(a, ops.conv2d(x, w, s, p, "nhwc"))
     assert np.array_equal(a, ops.conv2d(x, w, s, p, "nchw"))
+    ctx = R.get_ctx()
+    ctx.set_nchw_taps(2)   # k x k: the taps gathered from the channel planes instead of the transpose
+    try:
+        assert np.array_equal(a, ops.conv2d(x, w, s, p, "nchw"))
+    finally:
+        ctx.set_nchw_taps(1)
     if B * H * W <= 4000:
         want = O.conv2d(x, w, s, p)
         assert np.abs(a - want).max() <= 2e-6 * np.sqrt(Cin * k * k) * float(np.abs(want).max()) + 1e-6
@@ -838,6 +845,54 @@ def test_nchw_native_1x1_random_shapes(seed):
     assert np.array_equal(a, ops.conv2d(x, w, stride, 0, "nhwc")), (B, Cin, Cout, H, W, stride)
     want = O.conv2d(x, w, stride, 0)
     assert np.abs(a - want).max() <= 2e-6 * np.sqrt(Cin) * float(np.abs(want).max()) + 1e-6
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_nchw_native_kxk_random_shapes(seed):
+    """rn_conv_nchw.hip, k x k: tap (kh, kw) of a K tile gathered from the channel planes at
+    (s oh + kh - pad, s ow + kw - pad), zero in the padding; the packed panel as the MFMA rows.  Kernel sizes
+    1-7, paddings from none to more than the kernel needs, strides 1-3, planes down to one pixel, tiles that
+    straddle images, K below and above the chunked-sum threshold -- bit for bit the NHWC contraction (same K
+    order: taps outermost, 32 channels per tile), and within tolerance of the oracle."""
+    g = np.random.default_rng(4242 + seed)
+    k = int(g.choice([1, 3, 3, 3, 5, 7]))
+    pad = int(g.integers(0, k + 1)) if k > 1 else int(g.integers(0, 3))
+    stride = int(g.choice([1, 1, 2, 3]))
+    B = int(g.integers(1, 6))
+    H, W = int(g.integers(max(1, k - 2 * pad), 20)), int(g.integers(max(1, k - 2 * pad), 20))
+    Cin = 32 * int(g.choice([1, 2, 4, 8] if k > 3 else [1, 2, 3, 4, 8, 16]))
+    Cout = int(g.choice([1, 7, 63, 64, 65, 127, 128, 129, 200]))
+    x, w = rnd((B, Cin, H, W), 6200 + seed), rnd((Cout, Cin, k, k), 6300 + seed) / np.sqrt(Cin * k * k)
+    ctx = R.get_ctx()
+    ctx.set_nchw_taps(2)
+    try:
+        a = ops.conv2d(x, w, stride, pad, "nchw")
+    finally:
+        ctx.set_nchw_taps(1)
+    assert np.array_equal(a, ops.conv2d(x, w, stride, pad, "nhwc")), (B, Cin, Cout, H, W, k, stride, pad)
+    want = O.conv2d(x, w, stride, pad)
+    assert a.shape == want.shape
+    assert np.abs(a - want).max() <= 2e-6 * np.sqrt(Cin * k * k) * float(np.abs(want).max()) + 1e-6
+
+
+def test_nchw_native_kxk_is_a_choice_of_route_not_of_bits():
+    """rn_ctx_set_nchw_taps: 0 keeps the transposing route for every k x k layer on NCHW tensors, 2 takes the
+    gathering kernel wherever it is eligible, 1 (the default) takes it for planes of 2048 pixels or more (where it
+    measures faster, tools/nchw_bench.py): the same bits whichever runs, on a small plane and on a large one."""
+    ctx = R.get_ctx()
+    try:
+        for (B, Cin, Cout, H, W, s_) in ((3, 64, 96, 14, 14, 1), (2, 64, 64, 56, 56, 1), (2, 128, 128, 56, 56, 2)):
+            x, w = rnd((B, Cin, H, W), 6400 + H), rnd((Cout, Cin, 3, 3), 6401 + H) / np.sqrt(9 * Cin)
+            outs = []
+            for mode in (2, 1, 0):
+                ctx.set_nchw_taps(mode)
+                outs.append(ops.conv2d(x, w, s_, 1, "nchw"))
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+            assert np.array_equal(outs[0], ops.conv2d(x, w, s_, 1, "nhwc"))
+        with pytest.raises(R.RnError):
+            ctx.set_nchw_taps(3)
+    finally:
+        ctx.set_nchw_taps(1)
 
 
 @pytest.mark.parametrize("case", [(16, 7, 7, 512, 2048, 1, 1, 0),     # layer4 conv3: the shape the per-launch rule groups

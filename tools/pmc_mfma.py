@@ -32,7 +32,7 @@ import os
 import sys
 
 FAMILY = ("conv_gemm_kernel", "conv_wide_kernel", "conv_strip_kernel", "conv_strip128_kernel", "chain_kernel",
-          "chain32_", "splitk_finish_kernel", "stem_pool_kernel", "conv1x1_nchw_kernel", "conv_pair_kernel",
+          "chain32_", "splitk_finish_kernel", "stem_pool_kernel", "conv_nchw_kernel", "conv_pair_kernel",
           "conv_fused23_kernel")
 CUS, SIMDS, XCDS = 256, 4, 8
 
