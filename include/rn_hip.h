@@ -113,7 +113,10 @@ RN_API int rn_ctx_set_sync_each_op(rn_ctx *ctx, int on);
  * such a group is conv3 + bn + add + ReLU of a 64-channel bottleneck block and the next recorded group
  * is conv1 + bn + ReLU of the following block on that output, both run as one launch
  * (rn_conv_chain_forward_dt: the block output is written on its way to conv1; the same bits as the two
- * launches; RN_DEFER_CHAINS=0 in the environment keeps them apart).
+ * launches; RN_DEFER_CHAINS=0 in the environment keeps them apart).  The projection shortcut of a
+ * stage's first block (a convolution of the same output with its in-place batch-norm, main.cu:131-137)
+ * may stand between the two: it then runs right behind that launch, which nothing can observe as long as
+ * neither group names a buffer the other writes (checked; otherwise the call order is kept).
  * Contract for the caller: device memory it handed to the seven ops is read and written by other
  * means (own kernels, hipMemcpy) only after rn_observe(ctx, ptr) -- the C++ veneer's Tensor::data()
  * does that; weights and batch-norm parameters are cached in packed / folded form per buffer and the

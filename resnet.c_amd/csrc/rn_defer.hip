@@ -256,10 +256,80 @@ bool fusable_conv(const Op &c)
            c.B * (c.H + 2 * c.p) * (c.W + 2 * c.p) * c.Cin < lim;
 }
 
-// c = conv3 (1x1, 64 -> 256) with bn + add + ReLU folded, ops[j] = the convolution behind that group.  When that is
-// conv1 of the next block on c's output (1x1, 256 -> 64 | 128, bn and ReLU in place behind it) and every tensor is
-// already NHWC, both groups run as ONE launch (rn_conv_chain_forward_dt: the block output is written on its way
-// through LDS, so the caller's tensor holds its value as ever; the same bits as the two launches).  *done = taken.
+// every buffer a recorded op names: {pointer, bytes, written}
+struct Range {
+    const void *ptr;
+    uint64_t bytes;
+    bool write;
+};
+int op_ranges(const Op &o, Range r[7])
+{
+    const uint64_t f = sizeof(float);
+    int n = 0;
+    switch (o.kind) {
+    case K_CONV:
+        r[n++] = {o.in, o.B * o.Cin * o.H * o.W * f, false};
+        r[n++] = {o.w, o.Cout * o.Cin * o.k * o.k * f, false};
+        r[n++] = {o.out, o.B * o.Cout * o.ho * o.wo * f, true};
+        break;
+    case K_BN:
+        r[n++] = {o.in, o.B * o.Cout * o.N * f, false};
+        r[n++] = {o.w, o.Cout * f, false};
+        r[n++] = {o.b, o.Cout * f, false};
+        r[n++] = {o.mean, o.Cout * f, false};
+        r[n++] = {o.var, o.Cout * f, false};
+        r[n++] = {o.out, o.B * o.Cout * o.N * f, true};
+        break;
+    case K_RELU:
+        r[n++] = {o.in, o.N * f, false};
+        r[n++] = {o.out, o.N * f, true};
+        break;
+    case K_ADD:
+        r[n++] = {o.in, o.N * f, false};
+        r[n++] = {o.in2, o.N * f, false};
+        r[n++] = {o.out, o.N * f, true};
+        break;
+    case K_MAXPOOL:
+    case K_AVGPOOL:
+        r[n++] = {o.in, o.B * o.Cout * o.H * o.W * f, false};
+        r[n++] = {o.out, o.B * o.Cout * o.ho * o.wo * f, true};
+        break;
+    case K_LINEAR:
+        r[n++] = {o.in, o.B * o.Cin * f, false};
+        r[n++] = {o.w, o.Cout * o.Cin * f, false};
+        if (o.b) r[n++] = {o.b, o.Cout * f, false};
+        r[n++] = {o.out, o.B * o.Cout * f, true};
+        break;
+    }
+    return n;
+}
+
+// may ops [a0, a1) and ops [b0, b1) of the list run in either order?  (no buffer one group writes is named by the other)
+bool independent(const rn_defer_state *ds, size_t a0, size_t a1, size_t b0, size_t b1)
+{
+    Range ra[7], rb[7];
+    for (size_t a = a0; a < a1; ++a) {
+        const int na = op_ranges(ds->ops[a], ra);
+        for (size_t b = b0; b < b1; ++b) {
+            const int nb = op_ranges(ds->ops[b], rb);
+            for (int x = 0; x < na; ++x)
+                for (int y = 0; y < nb; ++y)
+                    if ((ra[x].write || rb[y].write) && overlaps(ra[x].ptr, ra[x].bytes, rb[y].ptr, rb[y].bytes)) return false;
+        }
+    }
+    return true;
+}
+
+int run_conv(rn_ctx *ctx, size_t i, size_t *next);
+int run_literal(rn_ctx *ctx, const Op &o);
+
+// c = conv3 (1x1, 64 -> 256) with bn + add + ReLU folded, ops[j] = the op behind that group.  When conv1 of the next
+// block follows on c's output (1x1, 256 -> 64 | 128, bn and ReLU in place behind it) and every tensor is already NHWC,
+// both groups run as ONE launch (rn_conv_chain_forward_dt: the block output is written on its way through LDS, so
+// the caller's tensor holds its value as ever; the same bits as the two launches).  One other convolution of c's
+// output with its in-place batch-norm / ReLU may stand between the two (the projection shortcut of a stage's first
+// block, main.cu:131-137, which the reference runs before conv1): it runs right after the launch instead of right
+// before conv1, which no buffer can tell when neither group names a buffer the other writes.  *done = taken.
 int try_chain(rn_ctx *ctx, const Op &c, const Op &bn, const float *r, size_t j, size_t *next, bool *done)
 {
     rn_defer_state *ds = ctx->ds;
@@ -267,21 +337,37 @@ int try_chain(rn_ctx *ctx, const Op &c, const Op &bn, const float *r, size_t j, 
     *done = false;
     if (!ds->chains || j >= n || ds->ops[j].kind != K_CONV) return RN_OK;
     if (!(c.k == 1 && c.s == 1 && c.p == 0 && c.Cin == 64 && c.Cout == 256 && c.ho == c.H && c.wo == c.W)) return RN_OK;
-    const Op c2 = ds->ops[j];
-    if (!(c2.in == c.out && c2.k == 1 && c2.s == 1 && c2.p == 0 && c2.Cin == 256 && (c2.Cout == 64 || c2.Cout == 128) &&
-          c2.B == c.B && c2.H == c.H && c2.W == c.W && c2.ho == c.H && c2.wo == c.W && fusable_conv(c2)))
-        return RN_OK;
     const uint64_t rows = c.B * c.H * c.W, f = sizeof(float);
     if (rows * 256 * f >= (1ull << 31)) return RN_OK;
-    size_t j2 = j + 1;
+    auto is_conv1 = [&](const Op &o) {
+        return o.kind == K_CONV && o.in == c.out && o.k == 1 && o.s == 1 && o.p == 0 && o.Cin == 256 &&
+               (o.Cout == 64 || o.Cout == 128) && o.B == c.B && o.H == c.H && o.W == c.W && o.ho == c.H && o.wo == c.W &&
+               fusable_conv(o);
+    };
+    // the in-place batch-norm / ReLU tail of the convolution at ops[at]: index of the first op behind it
+    auto tail_end = [&](size_t at, const Op **bn_, const Op **relu_) {
+        const Op &o = ds->ops[at];
+        size_t e = at + 1;
+        if (e < n && ds->ops[e].kind == K_BN && ds->ops[e].in == o.out && ds->ops[e].out == o.out &&
+            ds->ops[e].Cout == o.Cout && ds->ops[e].B == o.B && ds->ops[e].N == o.ho * o.wo)
+            *bn_ = &ds->ops[e++];
+        if (e < n && ds->ops[e].kind == K_RELU && ds->ops[e].in == o.out && ds->ops[e].out == o.out &&
+            ds->ops[e].N == o.B * o.Cout * o.ho * o.wo)
+            *relu_ = &ds->ops[e++];
+        return e;
+    };
+    size_t jx = j;  // [j, jx): the group that stands between, if any
+    if (!is_conv1(ds->ops[j])) {
+        if (ds->ops[j].in != c.out || ds->ops[j].out == c.out) return RN_OK;
+        const Op *b_ = nullptr, *r_ = nullptr;
+        jx = tail_end(j, &b_, &r_);
+        if (jx >= n || !is_conv1(ds->ops[jx])) return RN_OK;
+    }
+    const Op c2 = ds->ops[jx];
     const Op *bn2 = nullptr, *relu2 = nullptr;
-    if (j2 < n && ds->ops[j2].kind == K_BN && ds->ops[j2].in == c2.out && ds->ops[j2].out == c2.out &&
-        ds->ops[j2].Cout == c2.Cout && ds->ops[j2].B == c2.B && ds->ops[j2].N == c2.ho * c2.wo)
-        bn2 = &ds->ops[j2++];
-    if (j2 < n && ds->ops[j2].kind == K_RELU && ds->ops[j2].in == c2.out && ds->ops[j2].out == c2.out &&
-        ds->ops[j2].N == rows * c2.Cout)
-        relu2 = &ds->ops[j2++];
+    const size_t j2 = tail_end(jx, &bn2, &relu2);
     if (!relu2) return RN_OK;
+    if (jx > j && !independent(ds, j, jx, jx, j2)) return RN_OK;
     // the kernel reads its inputs a step ahead of the rows it writes: no output on top of an input or of the other
     const void *bufs[4] = {c.in, r, c.out, c2.out};
     const uint64_t sizes[4] = {rows * 64 * f, rows * 256 * f, rows * 256 * f, rows * c2.Cout * f};
@@ -302,6 +388,19 @@ int try_chain(rn_ctx *ctx, const Op &c, const Op &bn, const float *r, size_t j, 
     set_tag(ds, c.out, c.B, 256, c.H, c.W);
     set_tag(ds, c2.out, c.B, c2.Cout, c.H, c.W);
     ++ds->fused_launches;
+    // the group that stood between: now
+    for (size_t i = j; i < jx;) {
+        RN_TRY(settle_op(ctx, ds->ops[i]));
+        if (ds->ops[i].kind == K_CONV) {
+            size_t nx = i + 1;
+            RN_TRY(run_conv(ctx, i, &nx));
+            i = nx < jx ? nx : jx;
+        } else {
+            const Op o = ds->ops[i];
+            RN_TRY(run_literal(ctx, o));
+            ++i;
+        }
+    }
     *next = j2;
     *done = true;
     return RN_OK;

@@ -102,6 +102,15 @@ class Program:
                 self.steps.append(("relu", y, y))
                 if g.random() < 0.3:
                     self.steps.append((str(g.choice(["observe", "read", "partial", "flush"])), int(g.choice([y, r, src]))))
+                if g.random() < 0.4:
+                    # the projection shortcut of the next stage stands between (main.cu:131-137 runs it first); the
+                    # chain launch moves conv1 in front of it -- unless this group touches conv1's buffers
+                    d = conv1x1(y, 256, int(g.choice([32, 64])))
+                    self._bn(d, d)
+                    if g.random() < 0.3:
+                        self.steps.append(("relu", d, d))
+                    if g.random() < 0.15:
+                        self.steps.append(("add", d, d, d))
                 t1 = conv1x1(y, 256, int(g.choice([64, 128])))
                 if g.random() < 0.8:
                     self._bn(t1, t1)

@@ -47,8 +47,8 @@ def call(ctx, name, *args):
 
 def test_whole_network_deferred_matches_goldens_and_the_literal_route(state50, finch, golden_dir, dctx):
     """createResnet / resnetForward (the reference driver object for object, one C-ABI call per reference
-    op on NCHW tensors) on a deferred context: 51 fused launches for the 53 convolutions (conv3 of layer1's first
-    two blocks runs in one launch with conv1 of the block behind it), no literal batch-norm / ReLU / add pass,
+    op on NCHW tensors) on a deferred context: 50 fused launches for the 53 convolutions (conv3 of each of layer1's
+    blocks runs in one launch with conv1 of the block behind it), no literal batch-norm / ReLU / add pass,
     one layout pass for the input; logits within the bar of the reference module's goldens and within the
     fused epilogue's distance of the literal route; intermediate tensors come back as NCHW when observed."""
     x = np.concatenate([finch, R.weights.generate_input(2, seed=5)])
@@ -65,8 +65,8 @@ def test_whole_network_deferred_matches_goldens_and_the_literal_route(state50, f
     got = out.numpy()                                           # observed: the list runs
     s1 = dctx.deferred_stats()
     assert s1["pending_ops"] == 0
-    # every convolution with its in-place ops folded in; layer1: conv3 of blocks 0 and 1 + conv1 of the next, one launch
-    assert s1["fused_launches"] - s0["fused_launches"] == 51
+    # every convolution with its in-place ops folded in; layer1: conv3 of a block + conv1 of the next, one launch
+    assert s1["fused_launches"] - s0["fused_launches"] == 50
     assert s1["literal_launches"] - s0["literal_launches"] == 3  # max-pool, avg-pool, fc
     assert s1["transposes"] - s0["transposes"] == 1             # the NCHW input image -> padded NHWC
     want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
@@ -154,7 +154,14 @@ def test_conv3_of_a_block_and_conv1_of_the_next_run_as_one_launch(next_mid, dctx
     other = gpu(rnd((8,), g + 8))
     hw = H * W
 
-    def program(split):
+    wd = gpu(rnd((32, 256, 1, 1), g + 9, 1 / 16))
+    pd = bn_params(32, g + 10)
+    Pd = [gpu(v) for v in pd]
+    Hd, Wd = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    d = R.FloatTensor((B, 32, Hd, Wd), R.Device.GPU)
+    d_ = O.batchnorm2d_(O.conv2d(y_, rnd((32, 256, 1, 1), g + 9, 1 / 16), 2, 0), *pd)
+
+    def program(split, shortcut=False):
         call(dctx, "rn_conv2d_forward", D["x0"].data(), t2.data(), D["wa"].data(), 1, 1, 0, H, W, B, 64, 64, H, W)
         call(dctx, "rn_conv2d_forward", D["x1"].data(), r.data(), D["wb"].data(), 1, 1, 0, H, W, B, 64, 256, H, W)
         call(dctx, "rn_conv2d_forward", t2.data(), y.data(), D["w3"].data(), 1, 1, 0, H, W, B, 64, 256, H, W)
@@ -163,6 +170,9 @@ def test_conv3_of_a_block_and_conv1_of_the_next_run_as_one_launch(next_mid, dctx
         call(dctx, "rn_relu_forward", y.data(), y.data(), B * 256 * hw)
         if split:
             call(dctx, "rn_relu_forward", other.data(), other.data(), 8)
+        if shortcut:   # the next stage's projection shortcut (1x1 / 2 + bn) stands between, as main.cu:131-137 runs it
+            call(dctx, "rn_conv2d_forward", y.data(), d.data(), wd.data(), 1, 2, 0, Hd, Wd, B, 256, 32, H, W)
+            call(dctx, "rn_batchnorm2d_forward", d.data(), d.data(), *(t.data() for t in Pd), B, 32, Hd * Wd)
         call(dctx, "rn_conv2d_forward", y.data(), t1.data(), D["w1"].data(), 1, 1, 0, H, W, B, 256, next_mid, H, W)
         call(dctx, "rn_batchnorm2d_forward", t1.data(), t1.data(), *(t.data() for t in P1), B, next_mid, hw)
         call(dctx, "rn_relu_forward", t1.data(), t1.data(), B * next_mid * hw)
@@ -175,6 +185,9 @@ def test_conv3_of_a_block_and_conv1_of_the_next_run_as_one_launch(next_mid, dctx
     n_one, y_one, t1_one = program(False)
     assert (n_two, n_one) == (4, 3)
     assert np.array_equal(y_one, y_two) and np.array_equal(t1_one, t1_two)
+    n_sc, y_sc, t1_sc = program(False, shortcut=True)           # chain launch, then the shortcut: 4 launches, not 5
+    assert n_sc == 4 and np.array_equal(y_sc, y_one) and np.array_equal(t1_sc, t1_one)
+    assert np.abs(d.numpy() - d_).max() <= 3e-6 * 16 * float(np.abs(d_).max()) + 2e-5
     assert np.abs(y_one - y_) .max() <= 3e-6 * 8 * float(np.abs(y_).max()) + 1e-5
     assert np.abs(t1_one - t1_).max() <= 3e-6 * 16 * float(np.abs(t1_).max()) + 2e-5
     # a residual that is a plain NCHW tensor (not produced on this context): the two-launch form, same values
