@@ -50,10 +50,14 @@ def shard_bounds(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+_coord = {"rccl": False, "device": None, "mixed": False}
+
+
 def init_dist(world: int, backend: str = "nccl"):
     """Process group for the barrier / max-over-ranks only; returns (rank, local_rank).
-    The data path has no collective.  RCCL ("nccl") is used when it initialises; a node
-    where it cannot (e.g. ranks sharing one device in a rehearsal) falls back to gloo."""
+    The data path has no collective.  backend "nccl": RCCL for device tensors with gloo beside it for host
+    tensors (one group, "cpu:gloo,cuda:nccl") -- agree_on_rccl() then decides which half carries the
+    coordination; "gloo": host tensors only (ranks sharing one device in a rehearsal, CPU tests)."""
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,42 +65,62 @@ def init_dist(world: int, backend: str = "nccl"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        _coord["mixed"] = backend == "nccl"
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl" if backend == "nccl" else "gloo", rank=rank,
+                                world_size=world)
     return rank, local_rank
 
 
-_reduce_device = None
-
-
-def _coord_tensor(value: float):
-    """A 1-element tensor on whatever device the process group reduces on."""
+def agree_on_rccl(world: int, device) -> str:
+    """One all-reduce over RCCL on this rank's device.  If it works on EVERY rank (agreed through gloo) the
+    barrier and the max over ranks run on device tensors over RCCL / xGMI, otherwise -- RCCL raising on a node
+    where it cannot initialise -- on host tensors over gloo: the ranks still measure together, and the line
+    says which it was (`world.backend`).  Returns "nccl" or "gloo"; None for one process."""
+    if world == 1:
+        return None
     import torch
     import torch.distributed as dist
 
-    dev = _reduce_device if dist.get_backend() == "nccl" else None
-    return torch.tensor([value], dtype=torch.float64, device=dev)
+    ok = 0.0
+    if _coord["mixed"]:
+        try:
+            t = torch.ones(1, dtype=torch.float64, device=device)
+            dist.all_reduce(t)
+            torch.cuda.synchronize(device)
+            ok = 1.0 if int(t.item()) == world else 0.0
+        except Exception as e:  # noqa: BLE001 -- whatever RCCL raises, the host-side group still works
+            print(f"bench: RCCL all-reduce failed on rank {dist.get_rank()} ({type(e).__name__}: {str(e)[:200]}); "
+                  f"coordinating over gloo", file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # a host tensor: the gloo half
+        ok = float(flag.item())
+    _coord["rccl"], _coord["device"] = ok == 1.0, device
+    return "nccl" if _coord["rccl"] else "gloo"
+
+
+def _coord_tensor(value: float):
+    """A 1-element tensor where the process group coordinates: this rank's device (RCCL) or the host (gloo)."""
+    import torch
+
+    return torch.tensor([value], dtype=torch.float64, device=_coord["device"] if _coord["rccl"] else None)
 
 
 def barrier(world: int):
     if world > 1:
+        import torch
         import torch.distributed as dist
 
-        if dist.get_backend() == "nccl":
-            import torch
-
-            dist.barrier(device_ids=[torch.cuda.current_device()])
-        else:
-            dist.barrier()
+        t = _coord_tensor(0.0)
+        dist.all_reduce(t)
+        if _coord["rccl"]:
+            torch.cuda.synchronize(_coord["device"])
 
 
 def max_over_ranks(value: float, world: int, device=None) -> float:
     if world == 1:
         return value
-    import torch
     import torch.distributed as dist
 
-    global _reduce_device
-    _reduce_device = device
     t = _coord_tensor(value)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -131,14 +155,25 @@ def device_locality(device_index: int, bind: bool):
 
 
 def gather_ranks(me: dict, world: int):
-    """Every rank's own record (rank, device, its own ms_per_step ...) on every rank, in rank order."""
+    """Every rank's own record (rank, device, its own ms_per_step ...) on every rank, in rank order.
+    Host data: pickled and gathered as host tensors (the gloo half of the group, whichever half coordinates)."""
     if world == 1:
         return [me]
+    import pickle
+
+    import torch
     import torch.distributed as dist
 
-    ranks = [None] * dist.get_world_size()
-    dist.all_gather_object(ranks, me)
-    return ranks
+    n = dist.get_world_size()
+    blob = pickle.dumps(me)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(n)]
+    dist.all_gather(sizes, torch.tensor([len(blob)], dtype=torch.int64))
+    cap = max(int(x.item()) for x in sizes)
+    mine = torch.zeros(cap, dtype=torch.uint8)
+    mine[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+    bufs = [torch.zeros(cap, dtype=torch.uint8) for _ in range(n)]
+    dist.all_gather(bufs, mine)
+    return [pickle.loads(bytes(b[:int(x.item())].tolist())) for b, x in zip(bufs, sizes)]
 
 
 def world_block(ranks, size, backend):
@@ -334,7 +369,9 @@ def main():
     ndev = torch.cuda.device_count()
     if world > 1:
         assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run"
-    shared = world > ndev  # rehearsal on a box with fewer GPUs than ranks: ranks share devices
+    # rehearsal on a box with fewer GPUs than ranks: ranks share devices, which RCCL refuses -- host-side group
+    # (RN_BENCH_FORCE_RCCL=1 tries RCCL all the same: the rehearsal of the fall-back to gloo)
+    shared = world > ndev and os.environ.get("RN_BENCH_FORCE_RCCL", "0")[:1] != "1"
     rank, local_rank = init_dist(world, backend="gloo" if shared else "nccl")
     device_index = local_rank % max(ndev, 1)
     torch.cuda.set_device(device_index)
@@ -348,7 +385,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist_world, dist_backend = dist.get_world_size(), dist.get_backend()
+        dist_world, dist_backend = dist.get_world_size(), agree_on_rccl(world, torch.device("cuda", device_index))
     me.update(device_locality(device_index, bind=world > 1))
     print(f"bench: rank {rank}/{dist_world} ({dist_backend or 'single process'}) on cuda:{device_index} "
           f"{me['device']}", file=sys.stderr, flush=True)
