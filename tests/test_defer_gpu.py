@@ -83,6 +83,29 @@ def test_whole_network_deferred_matches_goldens_and_the_literal_route(state50, f
     assert np.array_equal(again, got)
 
 
+@pytest.mark.parametrize("arch,convs", [("resnet101", 104), ("resnet152", 155)])
+def test_deeper_networks_deferred_match_the_reference_modules_goldens(arch, convs, finch, golden_dir, dctx):
+    """ResNet-101 / 152 through the same reference-shaped driver on a deferred context: the logits of the finch
+    image and of the two random images within 1e-4 of the reference module's (tests/golden/make_golden.py), the
+    same values as the literal route within the folded batch-norm's distance; every convolution in a fused launch
+    (three of them shared: layer1's block boundaries)."""
+    state = R.weights.generate_state(arch, seed=0)
+    x = np.concatenate([finch, R.weights.generate_input(2, seed=7)])
+    m = R.createResnet(arch, state)
+    xd = gpu(x)
+    s0 = dctx.deferred_stats()
+    got = R.resnetForward(m, xd).numpy()
+    s1 = dctx.deferred_stats()
+    assert s1["fused_launches"] - s0["fused_launches"] == convs - 3 and s1["transposes"] - s0["transposes"] == 1
+    want = np.load(os.path.join(golden_dir, f"{arch}_finch_logits.npy"))
+    want2 = np.load(os.path.join(golden_dir, f"{arch}_rand2_logits.npy"))
+    assert np.abs(got[:1] - want).max() <= 1e-4 and np.abs(got[1:] - want2).max() <= 1e-4
+    dctx.set_deferred(False)
+    literal = R.resnetForward(m, xd).numpy()
+    dctx.set_deferred(True)
+    assert np.abs(got - literal).max() <= 5e-5 and np.array_equal(got.argmax(1), literal.argmax(1))
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 14, 14, 3, 1, 1), (3, 32, 96, 9, 7, 1, 1, 0), (2, 64, 128, 12, 12, 1, 2, 0),
                                   (1, 128, 32, 7, 7, 3, 2, 1), (2, 3, 64, 32, 32, 7, 2, 3)])
 def test_fused_chain_against_the_oracle(case, dctx):
