@@ -430,6 +430,14 @@ RN_API int rn_stem_pool_nchw_forward_dt(rn_ctx *ctx, int dtype, const float *inp
                                         const void *packed_weight, const float *scale,
                                         const float *shift, int relu, uint64_t B,
                                         uint64_t in_channels, uint64_t H, uint64_t W);
+/* The same launch for a caller that names the stem tensor as an output of its own (the reference does:
+ * main.cu:179-190 keeps conv -> bn -> relu in `act1`, then pools it): stem_out [B,Ho,Wo,64] = relu(bn(conv(x))),
+ * NHWC fp32, written from the registers that feed the pool, beside pool_out [B,PH,PW,64].  fp32, NCHW image
+ * [B,in_channels,H,W], W % 4 == 0; otherwise as rn_stem_pool_nchw_forward_dt.  What the deferred route
+ * (rn_ctx_set_deferred) runs for conv 7x7/2 -> bn -> relu -> maxpool 3x3/2/1. */
+RN_API int rn_stem_conv_pool_nchw_forward(rn_ctx *ctx, const float *inp_nchw, float *stem_out, float *pool_out,
+                                          const void *packed_weight, const float *scale, const float *shift,
+                                          uint64_t B, uint64_t in_channels, uint64_t H, uint64_t W);
 /* conv3 + bn3 + residual add + ReLU of one bottleneck block and conv1 + bn1 + ReLU of the next
  * (layerForward, main.cu:131-164, end of one pass and start of the next) as ONE launch on bf16 or
  * fp32 NHWC tensors: t2 [rows][mid] -> y [rows][channels] (written: the next block's residual) ->

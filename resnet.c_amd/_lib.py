@@ -113,6 +113,7 @@ SIGNATURES = {
     "rn_stem_pool_pack_weight_dt": (c_int, [c_void_p, c_int, fptr, fptr, u64]),
     "rn_stem_pool_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr, fptr, fptr, fptr, c_int, u64, u64, u64]),
     "rn_stem_pool_nchw_forward_dt": (c_int, [c_void_p, c_int, fptr, fptr, fptr, fptr, fptr, c_int, u64, u64, u64, u64]),
+    "rn_stem_conv_pool_nchw_forward": (c_int, [c_void_p] + [fptr] * 6 + [u64] * 4),
     "rn_conv_chain_forward_dt": (c_int, [c_void_p, c_int] + [fptr] * 10 + [u64] * 4),
     "rn_conv_chain_pair_forward_dt": (c_int, [c_void_p, c_int] + [fptr] * 9 + [u64] * 5),
     "rn_model_set_chain": (c_int, [c_void_p, c_int]),

@@ -58,10 +58,11 @@ struct Fold {  // batch-norm parameters folded to scale / shift (rn_batchnorm2d_
     float *scale, *shift;
 };
 
-struct ExactPack {  // exact-K panel of a small-Cin (stem) weight
+struct ExactPack {  // exact-K panel of a small-Cin (stem) weight, or (stem) the fused stem launch's register panel
     const float *w;
     uint64_t cin, cout, k;
     float *packed;
+    bool stem;
 };
 
 inline bool overlaps(const void *p, uint64_t n, const void *q, uint64_t m)
@@ -80,6 +81,9 @@ struct rn_defer_state {
     uint64_t fused_launches = 0, literal_launches = 0, transposes = 0;
     // conv3 of a 64-channel block + conv1 of the next as one launch (rn_chain.hip); RN_DEFER_CHAINS=0: A/B runs
     bool chains = !(getenv("RN_DEFER_CHAINS") && atoi(getenv("RN_DEFER_CHAINS")) == 0);
+    // the stem convolution + bn + ReLU and the max-pool behind it as one launch that writes both tensors
+    // (rn_stem_conv_pool_nchw_forward); RN_DEFER_STEM=0: A/B runs
+    bool stem = !(getenv("RN_DEFER_STEM") && atoi(getenv("RN_DEFER_STEM")) == 0);
 };
 
 namespace {
@@ -217,18 +221,20 @@ int packed_for(rn_ctx *ctx, const Op &c, const float **packed)
     return RN_OK;
 }
 
-int exact_for(rn_ctx *ctx, const Op &c, const float **packed)
+int exact_for(rn_ctx *ctx, const Op &c, const float **packed, bool stem = false)
 {
     rn_defer_state *ds = ctx->ds;
     for (const ExactPack &e : ds->exact)
-        if (e.w == c.w && e.cin == c.Cin && e.cout == c.Cout && e.k == c.k) {
+        if (e.w == c.w && e.cin == c.Cin && e.cout == c.Cout && e.k == c.k && e.stem == stem) {
             *packed = e.packed;
             return RN_OK;
         }
-    ExactPack e{c.w, c.Cin, c.Cout, c.k, nullptr};
-    RN_HIP_TRY(ctx, hipMalloc((void **)&e.packed,
-                              rn_conv2d_packed_weight_numel_exact(c.Cin, c.Cout, c.k) * sizeof(float)));
-    const int st = rn_conv2d_pack_weight_exact(ctx, c.w, e.packed, c.Cin, c.Cout, c.k);
+    ExactPack e{c.w, c.Cin, c.Cout, c.k, nullptr, stem};
+    const uint64_t numel = stem ? rn_stem_pool_packed_weight_numel(RN_DTYPE_F32)
+                                : rn_conv2d_packed_weight_numel_exact(c.Cin, c.Cout, c.k);
+    RN_HIP_TRY(ctx, hipMalloc((void **)&e.packed, numel * sizeof(float)));
+    const int st = stem ? rn_stem_pool_pack_weight_dt(ctx, RN_DTYPE_F32, c.w, e.packed, c.Cin)
+                        : rn_conv2d_pack_weight_exact(ctx, c.w, e.packed, c.Cin, c.Cout, c.k);
     if (st != RN_OK) {
         (void)hipFree(e.packed);
         return st;
@@ -482,6 +488,36 @@ int run_conv(rn_ctx *ctx, size_t i, size_t *next)
         RN_TRY(packed_for(ctx, c, &wp));
         st = rn_conv2d_nhwc_forward(ctx, x, c.out, wp, c.k, c.s, c.p, c.ho, c.wo, c.B, c.Cin, c.Cout, c.H, c.W, epp);
     } else {
+        // The reference's stem -- conv 7x7 / 2 / 3 to 64 channels, bn and ReLU in place, then max-pool 3x3 / 2 / 1 of
+        // that tensor into another (main.cu:179-192) -- is one launch that writes BOTH tensors, the stem tensor from the
+        // registers that feed the pool (rn_stem.hip, WRITE_Y), straight from the NCHW image: no layout pass, no
+        // second read of the largest tensor of the network
+        if (ds->stem && relu && !add && c.k == 7 && c.s == 2 && c.p == 3 && c.Cout == 64 && c.Cin <= 3 && j < n &&
+            ds->ops[j].kind == K_MAXPOOL) {
+            const Op pl = ds->ops[j];
+            const uint64_t ph = (c.ho + 2 - 3) / 2 + 1, pw = (c.wo + 2 - 3) / 2 + 1, f = sizeof(float);
+            const uint64_t patch = 48 + ((13 * (c.W + 6) * 3 * f + 15) & ~15ull);
+            const bool shapes = pl.in == c.out && pl.k == 3 && pl.s == 2 && pl.p == 1 && pl.B == c.B && pl.Cout == 64 &&
+                                pl.H == c.ho && pl.W == c.wo && pl.ho == ph && pl.wo == pw && c.ho >= 1 && c.wo >= 8 &&
+                                c.W % 4 == 0 && c.W <= 256 && c.wo % 8 == 0 && c.wo <= 128 && patch <= 48 * 1024 &&
+                                2 * patch + 5 * pw * 64 * f <= 160 * 1024 && c.ho * c.wo * 64 * f < (1ull << 31) &&
+                                c.B * ph * pw < (1ull << 31) && c.H + 6 < (1u << 14) &&
+                                (((uintptr_t)pl.out | (uintptr_t)c.in) & 15) == 0;
+            const uint64_t xin = c.B * c.Cin * c.H * c.W * f, yb = numel * f, pb = c.B * 64 * ph * pw * f;
+            if (shapes && !overlaps(pl.out, pb, c.out, yb) && !overlaps(pl.out, pb, c.in, xin) &&
+                !overlaps(c.out, yb, c.in, xin)) {
+                RN_TRY(settle_op(ctx, pl));
+                const float *wp = nullptr;
+                RN_TRY(exact_for(ctx, c, &wp, true));
+                RN_TRY(rn_stem_conv_pool_nchw_forward(ctx, c.in, c.out, pl.out, wp, ep.scale, ep.shift, c.B, c.Cin, c.H,
+                                                      c.W));
+                set_tag(ds, c.out, c.B, 64, c.ho, c.wo);
+                set_tag(ds, pl.out, c.B, 64, ph, pw);
+                ++ds->fused_launches;
+                *next = j + 1;
+                return RN_OK;
+            }
+        }
         // small Cin (the stem): NCHW image -> [B, H + 2p, W + 2p, Cin] with its zero border, exact-K panel
         const uint64_t Hp = c.H + 2 * c.p, Wp = c.W + 2 * c.p;
         void *xt = nullptr;

@@ -61,6 +61,7 @@ struct StemParams {
     const float *scale;  // folded batch-norm, may be null
     const float *shift;
     void *out;           // [B][PH][PW][64]
+    void *y;             // WRITE_Y: the stem tensor itself, [B][Ho][Wo][64] fp32 (relu(bn(conv))), else unused
     int B, Hp, Wp, Ho, Wo, PH, PW;
     int Cin;             // NCHW input only: channels of the image (1..3)
     int pairs;           // items per image: ceil(PH / 2)
@@ -93,9 +94,13 @@ struct Cfg<bf16_t> {
 // the patch is assembled in LDS from its channel rows -- zero border, channel interleave and the
 // conversion to T included -- and the separate layout kernel and its padded copy of the image
 // disappear.
-template <typename T, bool NCHW_IN>
+// WRITE_Y (fp32): the launch also writes the stem tensor -- for callers that name it as an output of their own
+// (the deferred route of the reference's op-by-op sequence, rn_defer.hip): every value leaves once, from the
+// registers of the epilogue that feeds the pool, 32 consecutive channels of a pixel per half-wave and store.
+template <typename T, bool NCHW_IN, bool WRITE_Y = false>
 __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
 {
+    static_assert(!WRITE_Y || sizeof(T) == 4, "the stem tensor is written in fp32 only");
     using C = Cfg<T>;
     constexpr int ES = (int)sizeof(T);
     constexpr int PIXB = C::CS * ES;            // bytes per pixel: 12 / 8
@@ -140,6 +145,10 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
     }
     const float sc = p.scale ? p.scale[n] : 1.f;
     const float sh = p.shift ? p.shift[n] : 0.f;
+    // WRITE_Y: this image of the stem tensor (Ho x Wo x 64 fp32: below 2^31 bytes, checked by the launcher)
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
+        WRITE_Y ? static_cast<char *>(p.y) + (size_t)b * p.Ho * p.Wo * kCout * 4 : nullptr, 0,
+        WRITE_Y ? p.Ho * p.Wo * kCout * 4 : 0, 0x00020000);
 
     for (int i = t; i < kRing * ring_row; i += 512) ring[i] = 0u;
     if constexpr (NCHW_IN) {  // the patches' border pixels and pad channel are zero and stay zero
@@ -362,6 +371,8 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
         // hundreds of registers.
         int li_ = li, lh_ = lh, wm_ = wm;
         asm volatile("" : "+v"(li_), "+v"(lh_), "+s"(wm_));
+        [[maybe_unused]] int n_ = n;
+        if constexpr (WRITE_Y) asm volatile("" : "+v"(n_));
         // ring rows of pooled rows 2pj, 2pj+1 (completed by this item) and 2pj+2 (its top row only)
         unsigned *const row0 = ring + ((2 * pj) % kRing) * ring_row;
         unsigned *const row1 = ring + ((2 * pj + 1) % kRing) * ring_row;
@@ -405,6 +416,18 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(const StemParams p)
                 const bool real = oh0 + dr < p.Ho;  // wave-uniform
 #pragma unroll
                 for (int i = 0; i < 4; ++i) y[dr][i] = real ? finish(acc[4 * dr + i]) : 0u;
+            }
+            if constexpr (WRITE_Y) {
+                // element (dr, i): stem row oh0 + dr, column 8 tile + 4 lh + i, channel n; rows past Ho do not exist
+                const int voff = ((8 * tile + 4 * lh_) * kCout + n_) * 4;
+#pragma unroll
+                for (int dr = 0; dr < 4; ++dr) {
+                    if (oh0 + dr >= p.Ho) continue;  // wave-uniform
+                    const int soff = (oh0 + dr) * p.Wo * kCout * 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b32(y[dr][i], rsrc_y, voff + i * kCout * 4, soff, 0);
+                }
             }
             // windows of pooled row 2pj: stem rows (4pj-1), 4pj, 4pj+1; of row 2pj+1: 4pj+1 .. 4pj+3;
             // of row 2pj+2: 4pj+3 (and the next item's first two)
@@ -503,7 +526,7 @@ int rn_stem_pool_pack_weight_dt(rn_ctx *ctx, int dtype, const float *weight_oihw
 // shared by the two entry points: nchw = the image is the reference's fp32 NCHW tensor, Cin channels
 static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, const void *packed_weight,
                             const float *scale, const float *shift, int relu, uint64_t B, uint64_t Hp,
-                            uint64_t Wp, bool nchw, uint64_t Cin, const char *what)
+                            uint64_t Wp, bool nchw, uint64_t Cin, const char *what, void *y = nullptr)
 {
     if (B == 0) return RN_OK;
     RN_REQUIRE(ctx, dtype == RN_DTYPE_F32 || dtype == RN_DTYPE_BF16, "unknown dtype");
@@ -532,8 +555,14 @@ static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, 
                    "bf16: the padded image width must be even (rows of whole 16-byte pieces)");
     }
     RN_REQUIRE(ctx, B * Hp * Wp * cs < (1ull << 40) && B * PH * PW < (1ull << 31), "tensor too large");
+    if (y) {
+        RN_REQUIRE(ctx, nchw && dtype == RN_DTYPE_F32, "the stem tensor is written by the fp32 NCHW-input form only");
+        RN_REQUIRE(ctx, y != out && y != inp && (reinterpret_cast<uintptr_t>(y) & 15) == 0, "aliased or misaligned stem tensor");
+        RN_REQUIRE(ctx, Ho * Wo * kCout * 4 < (1ull << 31), "stem tensor of one image too large");
+    }
     StemParams p;
     p.in = inp;
+    p.y = y;
     p.w = packed_weight;
     p.scale = scale;
     p.shift = shift;
@@ -581,10 +610,11 @@ static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, 
     const unsigned grid = (unsigned)(B * (uint64_t)p.segs);
     const bool bf = dtype == RN_DTYPE_BF16;
     const void *fn = bf ? (nchw ? (const void *)stem_pool_kernel<bf16_t, true> : (const void *)stem_pool_kernel<bf16_t, false>)
-                        : (nchw ? (const void *)stem_pool_kernel<float, true> : (const void *)stem_pool_kernel<float, false>);
+                        : (y ? (const void *)stem_pool_kernel<float, true, true>
+                             : nchw ? (const void *)stem_pool_kernel<float, true> : (const void *)stem_pool_kernel<float, false>);
     // more than 64 KB of dynamic LDS has to be allowed once per kernel and device (not a stream
     // operation: done on the first call, which a capturing caller makes eagerly anyway)
-    int *allowed = &ctx->occupancy[248 + (bf ? 1 : 0) + (nchw ? 2 : 0)];
+    int *allowed = &ctx->occupancy[y ? 252 : 248 + (bf ? 1 : 0) + (nchw ? 2 : 0)];
     if (lds_bytes > 64 * 1024 && *allowed == 0) {
         RN_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         *allowed = 1;
@@ -593,6 +623,8 @@ static int stem_pool_launch(rn_ctx *ctx, int dtype, const void *inp, void *out, 
         stem_pool_kernel<bf16_t, true><<<grid, 512, lds_bytes, ctx->stream>>>(p);
     else if (bf)
         stem_pool_kernel<bf16_t, false><<<grid, 512, lds_bytes, ctx->stream>>>(p);
+    else if (y)
+        stem_pool_kernel<float, true, true><<<grid, 512, lds_bytes, ctx->stream>>>(p);
     else if (nchw)
         stem_pool_kernel<float, true><<<grid, 512, lds_bytes, ctx->stream>>>(p);
     else
@@ -616,6 +648,17 @@ int rn_stem_pool_nchw_forward_dt(rn_ctx *ctx, int dtype, const float *inp_nchw, 
     RN_ENTER(ctx);
     return stem_pool_launch(ctx, dtype, inp_nchw, out, packed_weight, scale, shift, relu, B, H + 6, W + 6, true,
                             in_channels, "rn_stem_pool_nchw_forward_dt");
+}
+
+// the same launch writing the stem tensor as well: stem_out [B,Ho,Wo,64] = relu(bn(conv)) in NHWC, fp32
+int rn_stem_conv_pool_nchw_forward(rn_ctx *ctx, const float *inp_nchw, float *stem_out, float *pool_out,
+                                   const void *packed_weight, const float *scale, const float *shift, uint64_t B,
+                                   uint64_t in_channels, uint64_t H, uint64_t W)
+{
+    RN_ENTER(ctx);
+    RN_REQUIRE(ctx, stem_out != nullptr, "null tensor");
+    return stem_pool_launch(ctx, RN_DTYPE_F32, inp_nchw, pool_out, packed_weight, scale, shift, 1, B, H + 6, W + 6, true,
+                            in_channels, "rn_stem_conv_pool_nchw_forward", stem_out);
 }
 
 }  // extern "C"

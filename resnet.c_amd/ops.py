@@ -454,3 +454,29 @@ def stem_pool(x, w, scale=None, shift=None, relu_: bool = True, bf16: bool = Fal
     if bf16:
         host = (host.astype(np.uint32) << 16).view(np.float32)
     return np.ascontiguousarray(host.reshape(B, ph, pw, 64).transpose(0, 3, 1, 2))
+
+
+def stem_conv_pool(x, w, scale=None, shift=None):
+    """rn_stem_conv_pool_nchw_forward: the fused stem launch that also writes the stem tensor.  NCHW fp32 host
+    arrays in; (stem [B,64,Ho,Wo], pooled [B,64,PH,PW]) NCHW fp32 host arrays out."""
+    from .tensor import _DeviceBuffer
+    ctx, lib = get_ctx(), L.lib()
+    B, Cin, H, W = x.shape
+    assert w.shape == (64, Cin, 7, 7)
+    ho, wo = conv_output_size(H + 6, 7, 2, 0), conv_output_size(W + 6, 7, 2, 0)
+    ph, pw = conv_output_size(ho, 3, 2, 1), conv_output_size(wo, 3, 2, 1)
+    xin = FloatTensor.from_numpy(np.ascontiguousarray(x, dtype=np.float32), Device.GPU)
+    wd = FloatTensor.from_numpy(np.ascontiguousarray(w, dtype=np.float32), Device.GPU)
+    wp = _DeviceBuffer(ctx, int(lib.rn_stem_pool_packed_weight_numel(L.RN_DTYPE_F32)) * 4)
+    L.check(lib.rn_stem_pool_pack_weight_dt(ctx.handle, L.RN_DTYPE_F32, wd.data(), wp.ptr, Cin), "pack", ctx.handle)
+    sc = FloatTensor.from_numpy(np.asarray(scale, dtype=np.float32), Device.GPU) if scale is not None else None
+    sh = FloatTensor.from_numpy(np.asarray(shift, dtype=np.float32), Device.GPU) if shift is not None else None
+    y, out = _DeviceBuffer(ctx, B * ho * wo * 64 * 4), _DeviceBuffer(ctx, B * ph * pw * 64 * 4)
+    L.check(lib.rn_memset(ctx.handle, y.ptr, 0xFF, B * ho * wo * 64 * 4), "memset", ctx.handle)   # NaNs: every element must be written
+    L.check(lib.rn_stem_conv_pool_nchw_forward(ctx.handle, xin.data(), y.ptr, out.ptr, wp.ptr, sc.data() if sc else None,
+                                               sh.data() if sh else None, B, Cin, H, W), "stem_conv_pool", ctx.handle)
+    hy, hp = np.empty(B * ho * wo * 64, dtype=np.float32), np.empty(B * ph * pw * 64, dtype=np.float32)
+    L.check(lib.rn_memcpy_d2h(ctx.handle, hy.ctypes.data, y.ptr, hy.nbytes), "d2h", ctx.handle)
+    L.check(lib.rn_memcpy_d2h(ctx.handle, hp.ctypes.data, out.ptr, hp.nbytes), "d2h", ctx.handle)
+    return (np.ascontiguousarray(hy.reshape(B, ho, wo, 64).transpose(0, 3, 1, 2)),
+            np.ascontiguousarray(hp.reshape(B, ph, pw, 64).transpose(0, 3, 1, 2)))

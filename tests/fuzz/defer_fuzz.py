@@ -39,12 +39,34 @@ class Program:
         C0 = int(g.choice([32, 64, 96, 5, 3]))
         H = int(g.integers(4, 13))
         W = int(g.integers(4, 13))
+        stem = g.random() < 0.12
+        if stem:   # the reference's first four ops on an image the fused stem launch takes (or just not: W = 18, 20)
+            C0, H, W = int(g.choice([3, 3, 1])), int(g.integers(7, 24)), int(g.choice([16, 32, 32, 18, 20]))
         self.shapes = {0: (B, C0, H, W)}
         self.host = {0: g.standard_normal((B, C0, H, W), dtype=np.float32)}
         self.steps = []
         self.params = {}
         nxt = 1
         live = [0]
+        if stem:
+            # conv 7x7 / 2 / 3 -> bn -> relu in place, max-pool 3x3 / 2 / 1 into another tensor (main.cu:179-192):
+            # one launch that writes both tensors; sometimes a link is missing or something reads in between
+            ho, wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+            self.shapes[1] = (B, 64, ho, wo)
+            w = (g.standard_normal((64, C0, 7, 7), dtype=np.float32) / np.sqrt(C0 * 49)).astype(np.float32)
+            self.steps.append(("conv", 0, 1, 0, 7, 2, 3))
+            self.params[0] = [w]
+            live.append(1)
+            if g.random() < 0.85:
+                self._bn(1, 1)
+            if g.random() < 0.9:
+                self.steps.append(("relu", 1, 1))
+            if g.random() < 0.2:
+                self.steps.append((str(g.choice(["observe", "read", "partial", "flush"])), int(g.choice([0, 1]))))
+            self.shapes[2] = (B, 64, (ho + 2 - 3) // 2 + 1, (wo + 2 - 3) // 2 + 1)
+            self.steps.append(("maxpool", 1, 2, 3, 2, 1))
+            live.append(2)
+            nxt = 3
         n_ops = int(g.integers(4, 14))
         for _ in range(n_ops):
             kind = str(g.choice(["conv", "conv", "conv", "bn", "relu", "add", "maxpool", "avgpool", "observe", "read",

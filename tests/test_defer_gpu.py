@@ -48,8 +48,8 @@ def call(ctx, name, *args):
 def test_whole_network_deferred_matches_goldens_and_the_literal_route(state50, finch, golden_dir, dctx):
     """createResnet / resnetForward (the reference driver object for object, one C-ABI call per reference
     op on NCHW tensors) on a deferred context: 50 fused launches for the 53 convolutions (conv3 of each of layer1's
-    blocks runs in one launch with conv1 of the block behind it), no literal batch-norm / ReLU / add pass,
-    one layout pass for the input; logits within the bar of the reference module's goldens and within the
+    blocks runs in one launch with conv1 of the block behind it, the stem convolution with the max-pool), no
+    literal batch-norm / ReLU / add pass, no layout pass at all; logits within the bar of the reference module's goldens and within the
     fused epilogue's distance of the literal route; intermediate tensors come back as NCHW when observed."""
     x = np.concatenate([finch, R.weights.generate_input(2, seed=5)])
     dctx.set_deferred(False)
@@ -67,8 +67,8 @@ def test_whole_network_deferred_matches_goldens_and_the_literal_route(state50, f
     assert s1["pending_ops"] == 0
     # every convolution with its in-place ops folded in; layer1: conv3 of a block + conv1 of the next, one launch
     assert s1["fused_launches"] - s0["fused_launches"] == 50
-    assert s1["literal_launches"] - s0["literal_launches"] == 3  # max-pool, avg-pool, fc
-    assert s1["transposes"] - s0["transposes"] == 1             # the NCHW input image -> padded NHWC
+    assert s1["literal_launches"] - s0["literal_launches"] == 2  # avg-pool, fc (the max-pool: inside the stem launch)
+    assert s1["transposes"] - s0["transposes"] == 0             # the stem launch reads the NCHW image itself
     want = np.load(os.path.join(golden_dir, "resnet50_finch_logits.npy"))
     assert np.abs(got[:1] - want).max() <= 1e-4
     assert np.abs(got - literal).max() <= 5e-5
@@ -96,7 +96,7 @@ def test_deeper_networks_deferred_match_the_reference_modules_goldens(arch, conv
     s0 = dctx.deferred_stats()
     got = R.resnetForward(m, xd).numpy()
     s1 = dctx.deferred_stats()
-    assert s1["fused_launches"] - s0["fused_launches"] == convs - 3 and s1["transposes"] - s0["transposes"] == 1
+    assert s1["fused_launches"] - s0["fused_launches"] == convs - 3 and s1["transposes"] - s0["transposes"] == 0
     want = np.load(os.path.join(golden_dir, f"{arch}_finch_logits.npy"))
     want2 = np.load(os.path.join(golden_dir, f"{arch}_rand2_logits.npy"))
     assert np.abs(got[:1] - want).max() <= 1e-4 and np.abs(got[1:] - want2).max() <= 1e-4
@@ -226,6 +226,50 @@ def test_conv3_of_a_block_and_conv1_of_the_next_run_as_one_launch(next_mid, dctx
     dctx.flush()
     assert dctx.deferred_stats()["fused_launches"] - s0["fused_launches"] == 2
     assert np.abs(t1.numpy() - t1_).max() <= 3e-6 * 16 * float(np.abs(t1_).max()) + 2e-5
+
+
+@pytest.mark.parametrize("case", [(2, 3, 32, 32, True), (1, 3, 23, 48, True), (3, 1, 9, 16, True), (2, 3, 16, 20, False),
+                                  (2, 3, 32, 32, "no relu"), (2, 3, 32, 32, "reads between")])
+def test_stem_and_its_max_pool_run_as_one_launch_that_writes_both(case, dctx):
+    """The reference's first four ops (main.cu:179-192): conv 7x7 / 2 / 3 -> bn -> relu in place on `act1`, max-pool
+    3x3 / 2 / 1 of it into another tensor.  Deferred, they are ONE launch (rn_stem_conv_pool_nchw_forward) that reads
+    the NCHW image itself and writes BOTH tensors -- the stem tensor is the caller's and must hold its value -- when
+    the image suits the fused stem (W % 4 == 0, conv output width a multiple of 8); otherwise, or without the ReLU
+    (the pool is an integer maximum of non-negative bit patterns), or with a read in between, the separate launches.
+    Both tensors against the oracle; the pooled tensor is exactly the oracle's max-pool of the stem tensor read back."""
+    B, Cin, H, W, mode = case
+    x, w = rnd((B, Cin, H, W), 700 + H), rnd((64, Cin, 7, 7), 701 + H, 1.0 / np.sqrt(49 * Cin))
+    prm = bn_params(64, 702 + H)
+    ho, wo = O.conv_output_size(H, 7, 2, 3), O.conv_output_size(W, 7, 2, 3)
+    ph, pw = O.conv_output_size(ho, 3, 2, 1), O.conv_output_size(wo, 3, 2, 1)
+    y_ = O.batchnorm2d_(O.conv2d(x, w, 2, 3), *prm)
+    if mode != "no relu":
+        y_ = O.relu_(y_)
+    p_ = O.maxpool2d(y_, 3, 2, 1)
+    dx, dw, P = gpu(x), gpu(w), [gpu(v) for v in prm]
+    y, pl = R.FloatTensor((B, 64, ho, wo), R.Device.GPU), R.FloatTensor((B, 64, ph, pw), R.Device.GPU)
+    for _ in range(2):   # the second pass finds both tensors NHWC-tagged from the first
+        call(dctx, "rn_conv2d_forward", dx.data(), y.data(), dw.data(), 7, 2, 3, ho, wo, B, Cin, 64, H, W)
+        call(dctx, "rn_batchnorm2d_forward", y.data(), y.data(), *(t.data() for t in P), B, 64, ho * wo)
+        if mode != "no relu":
+            call(dctx, "rn_relu_forward", y.data(), y.data(), B * 64 * ho * wo)
+        if mode == "reads between":
+            assert np.abs(y.numpy() - y_).max() <= 2e-5 * max(1.0, float(np.abs(y_).max()))
+        call(dctx, "rn_maxpool2d_forward", y.data(), pl.data(), 3, 2, 1, ph, pw, B, 64, ho, wo)
+        s0 = dctx.deferred_stats()
+        dctx.flush()
+        s1 = dctx.deferred_stats()
+        d = {k: s1[k] - s0[k] for k in ("fused_launches", "literal_launches", "transposes")}
+        if mode is True:
+            assert d == {"fused_launches": 1, "literal_launches": 0, "transposes": 0}
+        elif mode == "reads between":
+            assert d == {"fused_launches": 0, "literal_launches": 1, "transposes": 0}   # only the pool was pending
+        else:
+            assert d == {"fused_launches": 1, "literal_launches": 1, "transposes": 1}
+        got_p, got_y = pl.numpy(), y.numpy()
+        tol = 3e-6 * np.sqrt(49 * Cin) * float(np.abs(y_).max()) + 1e-5
+        assert np.abs(got_y - y_).max() <= tol and np.abs(got_p - p_).max() <= tol
+        assert np.array_equal(got_p, O.maxpool2d(got_y, 3, 2, 1))
 
 
 def test_sequences_that_do_not_fold_run_literally_in_call_order(dctx):

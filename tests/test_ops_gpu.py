@@ -829,6 +829,23 @@ def test_fused_stem_refuses_what_it_cannot_do():
             assert e.value.status == L.RN_ERR_INVALID and "ReLU" in str(e.value)
 
 
+@pytest.mark.parametrize("case", [(2, 3, 224, 224), (3, 3, 32, 32), (1, 2, 23, 48), (5, 1, 9, 16), (2, 3, 61, 192)])
+def test_fused_stem_that_also_writes_the_stem_tensor(case):
+    """rn_stem_conv_pool_nchw_forward (stem_pool_kernel<float, NCHW, WRITE_Y>): the pooled tensor bit for bit what
+    rn_stem_pool_nchw_forward_dt gives (the same kernel body), the stem tensor -- every element written: the buffer
+    starts as NaNs -- within tolerance of the oracle's conv + affine + ReLU, and the pooled tensor exactly the
+    oracle's max-pool of the stem tensor that was written (it is the maximum of those very values)."""
+    B, Cin, H, W = case
+    x, w = rnd((B, Cin, H, W), 7300 + H), rnd((64, Cin, 7, 7), 7301 + H) / np.sqrt(49 * Cin)
+    sc, sh = np.random.default_rng(7302 + H).random(64, dtype=np.float32) + 0.5, rnd((64,), 7303 + H) * 0.2
+    y, pooled = ops.stem_conv_pool(x, w, sc, sh)
+    assert np.array_equal(pooled, ops.stem_pool(x, w, sc, sh, True, from_nchw=True))
+    want = np.maximum(O.conv2d(x, w, 2, 3) * sc[None, :, None, None] + sh[None, :, None, None], 0)
+    assert not np.isnan(y).any() and y.shape == want.shape
+    assert np.abs(y - want).max() <= 3e-6 * np.sqrt(49 * Cin) * float(np.abs(want).max()) + 1e-5
+    assert np.array_equal(pooled, O.maxpool2d(y, 3, 2, 1))
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_nchw_native_1x1_random_shapes(seed):
     """rn_conv_nchw.hip on random shapes: any batch, plane size (quads that straddle images, planes
