@@ -12,13 +12,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--route-only", action="store_true", help="only the NCHW op-by-op route, asynchronous (for a kernel trace)")
+ap.add_argument("--deferred-only", action="store_true", help="only the deferred route (for a kernel trace)")
 a = ap.parse_args()
 state = R.weights.generate_state("resnet50", 0)
 x_host = R.weights.generate_input(a.batch, 0)
 ctx = R.get_ctx()
 x = R.FloatTensor.from_numpy(x_host, R.Device.GPU)
 m = R.createResnet("resnet50", state)
-for sync, cache in (((False, False),) if a.route_only else ((True, False), (False, False), (False, True))):
+for sync, cache in (() if a.deferred_only else ((False, False),) if a.route_only else ((True, False), (False, False), (False, True))):
     ctx.set_sync_each_op(sync)
     ctx.set_weight_cache(cache)
     for _ in range(2):
@@ -54,6 +55,8 @@ s1 = ctx.deferred_stats()
 per = {k: (s1[k] - s0[k]) // a.steps for k in ("fused_launches", "literal_launches", "transposes")}
 print(f"NCHW op-by-op graph, DEFERRED (conv + in-place bn / add / relu folded, NHWC kept in the caller's buffers): "
       f"{dt*1e3:8.2f} ms/forward  {a.batch/dt:8.1f} img/s   per forward: {per}")
+if a.deferred_only:
+    sys.exit(0)
 logits_deferred = out.numpy()
 ctx.set_deferred(False)
 logits_literal = R.resnetForward(m, x).numpy()
