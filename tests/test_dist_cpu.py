@@ -31,6 +31,8 @@ def _worker(rank, world, port, q):
     # a stand-in "forward" with no cross-image reduction, run by the CPU checker
     w = R.weights.generate_tensor("conv1.weight", (4, 3, 3, 3), 0)
     y = O.conv2d(x.astype(np.float32), w, 1, 1).reshape(hi - lo, -1).sum(1)
+    # a host-side group (this test, rehearsals with ranks sharing a device): coordination over gloo, and it says so
+    assert bench.agree_on_rccl(world, None) == "gloo" and bench.agree_on_rccl(1, None) is None
     bench.barrier(world)
     t = bench.max_over_ranks(1.0 + rank, world)
     # the per-rank records of the bench line's `world` block: every rank's own time next to the max
