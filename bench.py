@@ -26,6 +26,10 @@ The JSON line also carries
   cpu_baseline  oracle/torch_port.py (a torch.nn.functional port of the reference's
                 pytorch_inference.py, pinned by the golden logits) timed on this host's
                 CPU cores on a bounded sample, rank 0 at N=1 only.
+  dropin_route  (fp32, N=1 only; never `value`) the reference's own caller shape on this engine: the
+                op-by-op graph of main.cu, one C-ABI call per reference op on NCHW tensors, on a deferred
+                context (the C++ veneer's default) and literally -- the unchanged caller's rate next to
+                the model driver's.
 """
 import argparse
 import json
@@ -333,6 +337,45 @@ def host_pipeline(model, x_host, B, fused, steps):
                     "overlapped = two slots in flight" % (x_host.nbytes / 1e6)}
 
 
+def dropin_route(arch: str, state, x_dev, B: int, steps: int):
+    """The reference's own caller shape on this engine (never `value`): createResnet / resnetForward, one C-ABI
+    call per reference op on NCHW fp32 tensors (main.cu:127-226), with the context deferred (what the C++ veneer
+    runs by default: conv + in-place bn / add / relu as one launch in the caller's buffers) and literally (one
+    launch per call).  Rates of the unchanged caller next to the model driver's `value`."""
+    import resnet_c_amd as R
+
+    ctx = R.get_ctx()
+    m = R.createResnet(arch, state)
+    out = {}
+    try:
+        for name, deferred in (("literal", False), ("deferred", True)):
+            ctx.set_deferred(deferred)
+            ctx.set_weight_cache(True)
+            for _ in range(2):
+                R.resnetForward(m, x_dev)
+                ctx.flush()
+            ctx.sync()
+            s0 = ctx.deferred_stats()
+            n = max(2, min(steps, 5))
+            t0 = time.perf_counter()
+            for _ in range(n):
+                R.resnetForward(m, x_dev)
+                ctx.flush()
+            ctx.sync()
+            dt = (time.perf_counter() - t0) / n
+            out[name] = {"images_per_s": round(B / dt, 1), "ms_per_forward": round(dt * 1e3, 3)}
+            if deferred:
+                s1 = ctx.deferred_stats()
+                out[name]["launches_per_forward"] = {k: (s1[k] - s0[k]) // n
+                                                     for k in ("fused_launches", "literal_launches", "transposes")}
+    finally:
+        ctx.set_deferred(False)
+        ctx.set_weight_cache(False)
+    out["what"] = ("the reference-shaped op-by-op graph (174 calls per ResNet-50 forward) on NCHW tensors: deferred = "
+                   "rn_ctx_set_deferred(1), literal = one launch per call; B = %d, inputs resident" % B)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,6 +389,8 @@ def main():
                     help="storage type of activations/weights (accumulation is always fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the leg that runs the reference's op-by-op caller shape (fp32, N = 1 only)")
     ap.add_argument("--no-tune", action="store_true", help="skip the per-layer tile tuning pass")
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2, 4],
                     help="parts of a batch that run on streams of their own (they fill each other's kernel "
@@ -568,6 +613,8 @@ def main():
     }
     if world == 1 and not args.no_pipeline:
         result["host_pipeline"] = host_pipeline(model, x_host, B, fused, args.steps)
+    if world == 1 and args.dtype == "f32" and not args.no_dropin:
+        result["dropin_route"] = dropin_route(args.arch, state, x_dev, B, args.steps)
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.arch, state, batch=B,
                                               engine=lambda a: model.forward(a, fused=fused))
